@@ -1,0 +1,27 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def kat():
+    return json.load(open(os.path.join(GOLDEN, "kat_reference.json")))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as orc
+    orc.lib()
+    return orc
