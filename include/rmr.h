@@ -1,0 +1,288 @@
+/*
+ * rmr.h -- C-ABI of librmr.so: the MI355X-native detect+locate hot path that
+ * replaces zmsbruce/rm_radar's Detector / RobotDetector / Locator back ends.
+ *
+ * The reference has no FFI: its boundary is the C++ class API of
+ * src/detect/detector.h, src/locate/locator.h and src/robot/robot.h
+ * (SURVEY.md 8b).  The C++20 wrappers in include/radar/ keep that API and call
+ * ONLY the functions below.  Every entry point cites the reference interface
+ * it stands in for (file:line under /root/reference).
+ *
+ * Conventions: plain pointers and sizes, opaque handles, caller-owned output
+ * buffers, int status returns (0 = ok), no exceptions cross this boundary.
+ * The library fails loudly (RMR_ERR_DEVICE) when no gfx950 device is usable;
+ * there is no CPU fallback.
+ */
+#ifndef RMR_H
+#define RMR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMR_ABI_VERSION 1
+
+typedef int rmr_status;
+enum {
+    RMR_OK = 0,
+    RMR_ERR_INVALID_ARGUMENT = 1, /* reference: std::invalid_argument (detector.cpp:80,181) */
+    RMR_ERR_RUNTIME = 2,          /* reference: std::runtime_error (detector.cpp:184,199,205) */
+    RMR_ERR_LOGIC = 3,            /* reference: std::logic_error (tensor.h:90) */
+    RMR_ERR_DEVICE = 4,           /* reference: CUDA_CHECK failure -> abort (common.h:54-62) */
+    RMR_ERR_CAPACITY = 5          /* a caller-owned or internal buffer was too small */
+};
+
+enum { RMR_MEM_HOST = 0, RMR_MEM_DEVICE = 1 };
+
+/* last error message of the calling thread ("" when none) */
+const char* rmr_last_error(void);
+int rmr_abi_version(void);
+/* number of usable gfx950 devices (0 => every create call returns RMR_ERR_DEVICE) */
+int rmr_device_count(void);
+
+/* ---------------------------------------------------------------- value types */
+
+/* cv::Mat as the hot path sees it: BGR u8, HWC, row stride in bytes
+ * (detector.cu:380-389).  mem says where `data` lives. */
+typedef struct {
+    const uint8_t* data;
+    int width, height, stride;
+    int mem;
+} rmr_image;
+
+/* radar::Detection (src/detect/detection.h:25-68): six f32, same layout */
+typedef struct {
+    float x, y, width, height, label, confidence;
+} rmr_detection;
+
+/* radar::detect::PreParam (src/detect/preparam.h:25-59) */
+typedef struct {
+    float width, height, ratio, dw, dh;
+} rmr_preparam;
+
+#define RMR_MAX_ARMORS 64
+
+/* radar::Robot as filled by detect + locate (src/robot/robot.h:53-164) */
+typedef struct {
+    float rect[4];       /* Rect2f x,y,w,h */
+    int has_label;       /* isDetected() */
+    int label;           /* radar::Label (robot.h:32-45) */
+    float confidence;
+    int n_armors;
+    rmr_detection armors[RMR_MAX_ARMORS];
+    int has_location;    /* isLocated() */
+    float location[3];   /* metres (robot.h:93-95) */
+} rmr_robot;
+
+/* compact fixed-size record used for the cross-GPU gather of the robot list */
+typedef struct {
+    float rect[4];
+    float location[3];
+    float confidence;
+    int32_t label;      /* -1 when not detected */
+    int32_t flags;      /* bit0 has_label, bit1 has_location */
+    int32_t stream_id;
+    int32_t frame_id;
+} rmr_robot_record;
+
+/* ---------------------------------------------------------------- geometry (host) */
+
+/* PreParam(cv::Size, cv::Size)  (preparam.h:46-52) */
+rmr_status rmr_preparam_make(int in_w, int in_h, int out_w, int out_h, rmr_preparam* out);
+/* resized size + border offsets as Detector::preprocess derives them (detector.cu:394-405) */
+rmr_status rmr_letterbox_geometry(const rmr_preparam* pp, int* resized_w, int* resized_h,
+                                  int* top, int* left);
+/* Detector::restoreDetection (detector.cpp:258-268) */
+rmr_status rmr_restore_detection(rmr_detection* d, const rmr_preparam* pp);
+
+/* ---------------------------------------------------------------- unit kernels */
+
+enum {
+    RMR_FMT_U8_HWC = 0,   /* letterboxed canvas, u8, same channel order as the source   */
+    RMR_FMT_F32_NCHW = 1  /* the reference's network input blob: f32 planar RGB * scale */
+};
+
+/* One fused launch standing in for resizeKernel + copyMakeBorderKernel + blobKernel
+ * (detector.cu:40-81, 102-133, 151-171) with explicit geometry, so the reference's
+ * kernel_test.cu vectors can be reproduced on the GPU.  For image i the sub-image
+ * crops[4i..4i+3] = (x,y,w,h) (NULL = whole image) is resized to (resized_w,resized_h),
+ * pasted at (left,top) into an out_w x out_h canvas filled with `fill`.
+ * `out` is a HOST buffer of n * out_w*out_h*3 elements (u8 or f32 by `fmt`). */
+rmr_status rmr_letterbox(int device, const rmr_image* imgs, const int* crops, int n,
+                         int resized_w, int resized_h, int top, int left, int out_w, int out_h,
+                         int fill, float scale, int fmt, void* out);
+
+/* Detector::preprocess (detector.cu:380-421, 439-502): geometry from PreParam, fill 128,
+ * scale 1/255, f32 NCHW RGB blob to a HOST buffer [n][3][out_h][out_w]; pp[n] out. */
+rmr_status rmr_preprocess(int device, const rmr_image* imgs, const int* crops, int n, int out_w,
+                          int out_h, float* blob, rmr_preparam* pp);
+
+/* Detector::postprocess (detector.cu:522-582): net_out is HOST [n][channels][anchors] f32
+ * (channels = 4 + classes).  Survivors per image in ascending anchor order, restored with
+ * pp[i]; out has room for cap detections per image; counts[i] = number found (may exceed
+ * cap: then only cap were written and RMR_ERR_CAPACITY is returned). */
+rmr_status rmr_postprocess(int device, const float* net_out, int n, int channels, int anchors,
+                           int classes, float nms_thresh, float conf_thresh,
+                           const rmr_preparam* pp, rmr_detection* out, int* counts, int cap);
+
+/* transposeKernel (detector.cu:185-203), kept only so its known-answer test has a target */
+rmr_status rmr_transpose(int device, const float* src, float* dst, int rows, int cols);
+
+/* One conv+bias(+SiLU)(+residual) layer through the MFMA implicit-GEMM engine.
+ * Host f32 in/out (converted to the engine's f16 NHWC internally): x [n][h][w][cin],
+ * w [cout][cin][kh][kw] (OIHW), bias [cout], residual/y [n][ho][wo][cout]. tile<0 = auto. */
+rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, const float* wt,
+                      const float* bias, int cout, int kh, int kw, int stride, int pad, int silu,
+                      const float* residual, float* y, int tile);
+
+/* ---------------------------------------------------------------- Detector */
+
+typedef struct rmr_detector rmr_detector;
+
+/* Detector::Detector arguments (detector.h:87-93).  engine_path names this library's
+ * weight pack (*.rmrw, see rm_radar_amd/weights.py) instead of a TensorRT engine. */
+typedef struct {
+    const char* engine_path;
+    int classes;
+    int image_width, image_height; /* cv::Size image_size: sizes the staging buffer */
+    int max_batch_size;
+    int opt_batch_size;            /* <=0 : nullopt */
+    float nms_thresh, conf_thresh; /* 0.65 / 0.25 */
+    int input_width, input_height; /* 640 x 640 */
+    int input_channels;            /* 3 */
+    int device;                    /* the reference hard-wires cudaSetDevice(0) (detector.cpp:61) */
+} rmr_detector_cfg;
+
+void rmr_detector_cfg_default(rmr_detector_cfg* cfg);
+rmr_status rmr_detector_create(const rmr_detector_cfg* cfg, rmr_detector** out);
+void rmr_detector_destroy(rmr_detector* det);
+
+/* Detector::detect<T> (detector.h:117-134) for n images (n=1: the cv::Mat overload).
+ * crops may be NULL.  out: cap detections per image; counts[n]. */
+rmr_status rmr_detector_detect(rmr_detector* det, const rmr_image* imgs, const int* crops, int n,
+                               rmr_detection* out, int* counts, int cap);
+/* preprocess + network only: the tensor TensorRT hands to postprocess,
+ * HOST [n][4+classes][anchors] f32 (detector.cpp:129-130); pp[n] optional. */
+rmr_status rmr_detector_infer(rmr_detector* det, const rmr_image* imgs, const int* crops, int n,
+                              float* net_out, rmr_preparam* pp);
+int rmr_detector_anchors(const rmr_detector* det);
+int rmr_detector_channels(const rmr_detector* det);
+/* algorithmic FLOPs of one 640x640 forward (2*MAC over all convs) */
+double rmr_detector_flops_per_image(const rmr_detector* det);
+
+/* ---------------------------------------------------------------- RobotDetector */
+
+typedef struct rmr_robot_detector rmr_robot_detector;
+
+/* RobotDetector::RobotDetector arguments (detector.h:173-180) */
+typedef struct {
+    const char* car_engine_path;
+    const char* armor_engine_path;
+    int image_width, image_height;
+    int armor_classes;
+    int max_cars, opt_cars;
+    float iou_thresh;                         /* 0.75 */
+    float car_nms_thresh, car_conf_thresh;    /* 0.65 / 0.25 */
+    float armor_nms_thresh, armor_conf_thresh;/* 0.65 / 0.50 */
+    int input_width, input_height, input_channels;
+    int device;
+    int max_frames;                           /* frames per detect_batch call (>=1) */
+} rmr_robot_detector_cfg;
+
+void rmr_robot_detector_cfg_default(rmr_robot_detector_cfg* cfg);
+rmr_status rmr_robot_detector_create(const rmr_robot_detector_cfg* cfg, rmr_robot_detector** out);
+void rmr_robot_detector_destroy(rmr_robot_detector* rd);
+/* RobotDetector::detect (detector.cpp:413-455): one frame -> robots (cap entries) */
+rmr_status rmr_robot_detector_detect(rmr_robot_detector* rd, const rmr_image* img, rmr_robot* out,
+                                     int* n_out, int cap);
+/* throughput mode: n_frames independent frames in one call (car stage batched over frames,
+ * armor stage batched over all crops).  forced_crops != NULL injects forced_per_frame crop
+ * rects (x,y,w,h) per frame in place of the car detections (synthetic-weight benches);
+ * the car stage still runs in full.  out: cap robots per frame; n_out[n_frames]. */
+rmr_status rmr_robot_detector_detect_batch(rmr_robot_detector* rd, const rmr_image* imgs,
+                                           int n_frames, const int* forced_crops,
+                                           int forced_per_frame, rmr_robot* out, int* n_out,
+                                           int cap);
+/* host-side pieces, exposed for parity tests (robot.cpp:41-74, detector.cpp:324-349, 427-454) */
+rmr_status rmr_robot_set_detection(rmr_robot* r, const rmr_detection* car,
+                                   const rmr_detection* armors, int n_armors);
+float rmr_compute_iou(const float rect_a[4], const float rect_b[4]);
+rmr_status rmr_group_robots(const rmr_robot* in, int n, float iou_thresh, rmr_robot* out,
+                            int* n_out);
+
+/* ---------------------------------------------------------------- Locator */
+
+typedef struct rmr_locator rmr_locator;
+
+/* Locator::Locator arguments (locator.h:59-65) */
+typedef struct {
+    int image_width, image_height;
+    float intrinsic[9];        /* cv::Matx33f row-major */
+    float lidar_to_camera[16]; /* cv::Matx44f row-major */
+    float world_to_camera[16];
+    float zoom_factor;         /* 0.5 */
+    int queue_size;            /* 3 */
+    float min_depth_diff, max_depth_diff; /* 500 / 4000 mm */
+    float cluster_tolerance;   /* 400 mm */
+    int min_cluster_size, max_cluster_size; /* 8 / 1000 */
+    float max_distance;        /* 29300 mm */
+    int device;
+    int max_points;            /* capacity of one cloud (default 262144) */
+    int max_foreground;        /* capacity of the foreground list (default 32768) */
+    int max_frames;            /* per-frame results kept for batched search (default 1) */
+} rmr_locator_cfg;
+
+void rmr_locator_cfg_default(rmr_locator_cfg* cfg);
+rmr_status rmr_locator_create(const rmr_locator_cfg* cfg, rmr_locator** out);
+void rmr_locator_destroy(rmr_locator* loc);
+/* Locator::update (locate.cpp:158-220).  xyz: first of n points, stride_bytes apart
+ * (16 for pcl::PointXYZ), millimetres.  NULL / n<=0 = the reference's null/empty cloud. */
+rmr_status rmr_locator_update(rmr_locator* loc, const float* xyz, int n, int stride_bytes, int mem);
+/* Locator::cluster (locate.cpp:231-264) */
+rmr_status rmr_locator_cluster(rmr_locator* loc);
+/* Locator::search(std::vector<Robot>&) (locate.cpp:323-326): fills location / has_location */
+rmr_status rmr_locator_search(rmr_locator* loc, rmr_robot* robots, int n);
+/* keep the current frame's cluster() result in slot `frame` (0..max_frames-1), and search
+ * robots against a kept slot: lets a batch of frames be located after a batched detect */
+rmr_status rmr_locator_keep(rmr_locator* loc, int frame);
+rmr_status rmr_locator_search_kept(rmr_locator* loc, int frame, rmr_robot* robots, int n);
+
+/* private members the reference's tests reach via `#define private public`
+ * (test/locate/locator_test.cpp:6-13) */
+enum { RMR_LOC_DEPTH = 0, RMR_LOC_BACKGROUND = 1, RMR_LOC_DIFF = 2 };
+enum { RMR_XF_LIDAR_TO_WORLD = 0, RMR_XF_CAMERA_TO_LIDAR = 1, RMR_XF_LIDAR_TO_CAMERA = 2 };
+int rmr_locator_width(const rmr_locator* loc);  /* image_width_zoomed_ */
+int rmr_locator_height(const rmr_locator* loc);
+rmr_status rmr_locator_read_image(rmr_locator* loc, int which, float* host_out);
+rmr_status rmr_locator_write_image(rmr_locator* loc, int which, const float* host_in);
+rmr_status rmr_locator_transform(const rmr_locator* loc, int which, const float in[3], float out[3]);
+rmr_status rmr_locator_zoom(const rmr_locator* loc, const int rect[4], int out[4]);
+/* cluster() products: foreground points in scan order (lidar frame, mm), their pixel
+ * (v*W+u) and cluster id (-1 = unclustered); clusters_.size() */
+rmr_status rmr_locator_foreground(rmr_locator* loc, float* xyz, int* pixel, int* cluster, int cap,
+                                  int* n);
+int rmr_locator_num_clusters(rmr_locator* loc);
+
+/* ---------------------------------------------------------------- per-kernel profile */
+
+/* HIP-event timing of the library's own launches, on the streams they run on */
+typedef struct {
+    char name[48];
+    long long launches;
+    double total_ms;
+    double flops;  /* algorithmic FLOPs summed over the launches */
+    double bytes;  /* algorithmic HBM bytes summed over the launches */
+} rmr_kernel_stat;
+
+rmr_status rmr_profile_enable(int device, int on);
+rmr_status rmr_profile_reset(int device);
+/* resolves pending events (synchronises), writes up to cap entries, *n = entries available */
+rmr_status rmr_profile_read(int device, rmr_kernel_stat* out, int cap, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMR_H */

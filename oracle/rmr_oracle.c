@@ -139,8 +139,8 @@ void orc_decode(const float* src, orc_detection* dst, int channels, int anchors,
             if (score[j] > score[best]) best = j;
         double xd = (double)bbox[0] - 0.5 * (double)bbox[2];
         double yd = (double)bbox[1] - 0.5 * (double)bbox[3];
-        dst[row].x = (float)(xd > 0.0 ? xd : 0.0);
-        dst[row].y = (float)(yd > 0.0 ? yd : 0.0);
+        dst[row].x = (float)fmax(xd, 0.0);
+        dst[row].y = (float)fmax(yd, 0.0);
         dst[row].width = bbox[2];
         dst[row].height = bbox[3];
         dst[row].label = (float)best;
@@ -150,11 +150,11 @@ void orc_decode(const float* src, orc_detection* dst, int channels, int anchors,
 
 /* src/detect/detector.cu:271-293 (Q8) */
 float orc_iou(float x1, float y1, float w1, float h1, float x2, float y2, float w2, float h2) {
-    float x_left = x1 > x2 ? x1 : x2;
-    float y_top = y1 > y2 ? y1 : y2;
-    float r1 = x1 + w1, r2 = x2 + w2, b1 = y1 + h1, b2 = y2 + h2;
-    float x_right = r1 < r2 ? r1 : r2;
-    float y_bottom = b1 < b2 ? b1 : b2;
+    /* CUDA max/min on floats are fmaxf/fminf (a NaN operand yields the other one) */
+    float x_left = fmaxf(x1, x2);
+    float y_top = fmaxf(y1, y2);
+    float x_right = fminf(x1 + w1, x2 + w2);
+    float y_bottom = fminf(y1 + h1, y2 + h2);
     if (x_right < x_left || y_bottom < y_top) return 0.0f;
     float iw = x_right - x_left;
     float ih = y_bottom - y_top;

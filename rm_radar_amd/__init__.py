@@ -1,0 +1,503 @@
+"""rm_radar_amd -- MI355X-native detect + locate hot path of zmsbruce/rm_radar.
+
+Host-side mirror (Python) of the reference's C++ interface for this path -- ``Detector``,
+``RobotDetector``, ``Locator``, ``Robot``, ``Detection``, ``PreParam`` -- over the C-ABI of
+``librmr.so`` (include/rmr.h).  All compute is hand-written HIP for gfx950 inside that
+library; there is no CPU fallback and importing this package never touches ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CapacityError, DET_DTYPE, DeviceError, InvalidArgument, PreParam, RmrError,
+                   check, lib)
+
+__all__ = ["Detector", "RobotDetector", "Locator", "Robot", "PreParam", "preparam",
+           "letterbox_geometry", "letterbox", "preprocess", "postprocess", "transpose",
+           "conv2d", "restore_detection", "device_count", "profile", "DET_DTYPE", "RmrError",
+           "InvalidArgument", "DeviceError", "CapacityError", "Label"]
+
+# radar::Label (src/robot/robot.h:32-45)
+Label = {"BlueHero": 0, "BlueEngineer": 1, "BlueInfantryThree": 2, "BlueInfantryFour": 3,
+         "BlueInfantryFive": 4, "RedHero": 5, "RedEngineer": 6, "RedInfantryThree": 7,
+         "RedInfantryFour": 8, "RedInfantryFive": 9, "BlueSentry": 10, "RedSentry": 11}
+
+
+def device_count() -> int:
+    return lib().rmr_device_count()
+
+
+# ------------------------------------------------------------------------------- images
+
+def _is_device_tensor(obj) -> bool:
+    return hasattr(obj, "data_ptr") and getattr(obj, "is_cuda", False)
+
+
+def _as_image(obj, keep: list) -> _lib.Image:
+    """numpy HxWx3 u8 (host) or a torch CUDA tensor of that shape (device) -> rmr_image."""
+    if _is_device_tensor(obj):
+        if obj.dim() != 3 or obj.shape[2] != 3 or obj.element_size() != 1:
+            raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "device image must be HxWx3 uint8")
+        if obj.stride(2) != 1 or obj.stride(1) != 3:
+            raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "device image pixels must be packed BGR")
+        keep.append(obj)
+        return _lib.Image(obj.data_ptr(), obj.shape[1], obj.shape[0], obj.stride(0), _lib.MEM_DEVICE)
+    a = np.asarray(obj)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "image must be HxWx3 uint8 (BGR)")
+    if a.strides[2] != 1 or a.strides[1] != 3:
+        a = np.ascontiguousarray(a)
+    keep.append(a)
+    return _lib.Image(a.ctypes.data, a.shape[1], a.shape[0], a.strides[0], _lib.MEM_HOST)
+
+
+def _images(images, crops):
+    keep: list = []
+    arr = (_lib.Image * len(images))(*[_as_image(im, keep) for im in images])
+    cr = None
+    if crops is not None:
+        cr = np.ascontiguousarray(np.asarray(crops, np.int32).reshape(len(images), 4))
+        keep.append(cr)
+    return arr, (_lib.ip(cr) if cr is not None else None), keep
+
+
+# ------------------------------------------------------------------------------- geometry
+
+def preparam(in_w: int, in_h: int, out_w: int = 640, out_h: int = 640) -> PreParam:
+    """radar::detect::PreParam(cv::Size input, cv::Size output)  (preparam.h:46-52)"""
+    p = PreParam()
+    check(lib().rmr_preparam_make(in_w, in_h, out_w, out_h, C.byref(p)))
+    return p
+
+
+def letterbox_geometry(p: PreParam):
+    v = [C.c_int() for _ in range(4)]
+    check(lib().rmr_letterbox_geometry(C.byref(p), *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)  # resized_w, resized_h, top, left
+
+
+def restore_detection(det, p: PreParam):
+    d = _lib.Detection(*[float(v) for v in det])
+    check(lib().rmr_restore_detection(C.byref(d), C.byref(p)))
+    return (d.x, d.y, d.width, d.height, d.label, d.confidence)
+
+
+# ------------------------------------------------------------------------------- unit kernels
+
+def letterbox(images, resized_w, resized_h, top, left, out_w, out_h, fill=128, scale=1.0,
+              fmt="u8", crops=None, device=0):
+    """Fused resize + border (+ blob) with explicit geometry (detector.cu:40-171)."""
+    arr, cr, keep = _images(images, crops)
+    n = len(images)
+    if fmt == "u8":
+        out = np.empty((n, out_h, out_w, 3), np.uint8)
+        code = _lib.FMT_U8_HWC
+    else:
+        out = np.empty((n, 3, out_h, out_w), np.float32)
+        code = _lib.FMT_F32_NCHW
+    check(lib().rmr_letterbox(device, arr, cr, n, resized_w, resized_h, top, left, out_w, out_h,
+                              fill, scale, code, out.ctypes.data))
+    return out
+
+
+def preprocess(images, crops=None, out_w=640, out_h=640, device=0):
+    """Detector::preprocess (detector.cu:380-502) -> (blob [n,3,h,w] f32, [PreParam])."""
+    arr, cr, keep = _images(images, crops)
+    n = len(images)
+    blob = np.empty((n, 3, out_h, out_w), np.float32)
+    pps = (PreParam * n)()
+    check(lib().rmr_preprocess(device, arr, cr, n, out_w, out_h, _lib.fp(blob), pps))
+    return blob, list(pps)
+
+
+def postprocess(net_out, classes, nms_thresh, conf_thresh, pps, cap=None, device=0):
+    """Detector::postprocess (detector.cu:522-582): [n, 4+classes, anchors] -> list of arrays."""
+    net_out = np.ascontiguousarray(net_out, np.float32)
+    n, ch, a = net_out.shape
+    cap = cap or a
+    out = np.empty((n, cap), DET_DTYPE)
+    counts = np.zeros(n, np.int32)
+    pp = (PreParam * n)(*pps)
+    check(lib().rmr_postprocess(device, _lib.fp(net_out), n, ch, a, classes, nms_thresh,
+                                conf_thresh, pp, out.ctypes.data, _lib.ip(counts), cap))
+    return [out[i, :counts[i]].copy() for i in range(n)]
+
+
+def transpose(src, device=0):
+    src = np.ascontiguousarray(src, np.float32)
+    r, c = src.shape
+    dst = np.empty((c, r), np.float32)
+    check(lib().rmr_transpose(device, _lib.fp(src), _lib.fp(dst), r, c))
+    return dst
+
+
+def conv2d(x_nhwc, w_oihw, bias, stride, pad, silu, residual=None, tile=-1, device=0):
+    """One conv(+bias)(+SiLU)(+residual) layer through the MFMA implicit-GEMM engine."""
+    x = np.ascontiguousarray(x_nhwc, np.float32)
+    w = np.ascontiguousarray(w_oihw, np.float32)
+    n, h, wd, cin = x.shape
+    cout, cin2, kh, kw = w.shape
+    assert cin2 == cin
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (wd + 2 * pad - kw) // stride + 1
+    y = np.empty((n, ho, wo, cout), np.float32)
+    b = np.ascontiguousarray(bias, np.float32) if bias is not None else np.zeros(cout, np.float32)
+    r = np.ascontiguousarray(residual, np.float32) if residual is not None else None
+    check(lib().rmr_conv2d(device, _lib.fp(x), n, h, wd, cin, _lib.fp(w), _lib.fp(b), cout, kh, kw,
+                           stride, pad, int(bool(silu)), _lib.fp(r) if r is not None else None,
+                           _lib.fp(y), tile))
+    return y
+
+
+# ------------------------------------------------------------------------------- Robot
+
+@dataclass
+class Robot:
+    """radar::Robot as filled by detect + locate (src/robot/robot.h:53-164)."""
+    rect: tuple = (0.0, 0.0, 0.0, 0.0)
+    label: Optional[int] = None
+    confidence: Optional[float] = None
+    armors: Optional[np.ndarray] = None
+    location: Optional[tuple] = None
+
+    def is_detected(self) -> bool:
+        return self.armors is not None
+
+    def is_located(self) -> bool:
+        return self.location is not None
+
+    @staticmethod
+    def from_c(r: _lib.Robot) -> "Robot":
+        armors = None
+        if r.has_label:
+            armors = np.array([(a.x, a.y, a.width, a.height, a.label, a.confidence)
+                               for a in r.armors[: r.n_armors]], DET_DTYPE)
+        return Robot(rect=tuple(r.rect), label=r.label if r.has_label else None,
+                     confidence=r.confidence if r.has_label else None, armors=armors,
+                     location=tuple(r.location) if r.has_location else None)
+
+    def to_c(self) -> _lib.Robot:
+        r = _lib.Robot()
+        r.rect[:] = [float(v) for v in self.rect]
+        r.has_label = int(self.label is not None)
+        r.label = self.label if self.label is not None else -1
+        r.confidence = self.confidence or 0.0
+        if self.armors is not None:
+            r.n_armors = len(self.armors)
+            for i, a in enumerate(self.armors):
+                r.armors[i] = _lib.Detection(*[float(v) for v in a])
+        if self.location is not None:
+            r.has_location = 1
+            r.location[:] = [float(v) for v in self.location]
+        return r
+
+    @staticmethod
+    def from_detection(car, armors) -> "Robot":
+        """Robot::Robot(const Detection& car, const std::vector<Detection>& armors)"""
+        r = _lib.Robot()
+        c = _lib.Detection(*[float(v) for v in car])
+        armors = np.ascontiguousarray(armors, DET_DTYPE)
+        check(lib().rmr_robot_set_detection(C.byref(r), C.byref(c), armors.ctypes.data, len(armors)))
+        return Robot.from_c(r)
+
+
+def compute_iou(a, b) -> float:
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    return lib().rmr_compute_iou(_lib.fp(a), _lib.fp(b))
+
+
+def group_robots(robots: Sequence[Robot], iou_thresh: float) -> List[Robot]:
+    n = len(robots)
+    arr = (_lib.Robot * max(n, 1))(*[r.to_c() for r in robots])
+    out = (_lib.Robot * max(n, 1))()
+    m = C.c_int()
+    check(lib().rmr_group_robots(arr, n, iou_thresh, out, C.byref(m)))
+    return [Robot.from_c(out[i]) for i in range(m.value)]
+
+
+# ------------------------------------------------------------------------------- Detector
+
+class Detector:
+    """radar::Detector (src/detect/detector.h:84-169).  ``engine_path`` names a weight pack
+    (rm_radar_amd.weights) instead of a TensorRT engine."""
+
+    def __init__(self, engine_path, classes, image_size, max_batch_size, opt_batch_size=None,
+                 nms_thresh=0.65, conf_thresh=0.25, input_width=640, input_height=640,
+                 input_name="images", input_channels=3, opt_level=3, device=0):
+        cfg = _lib.DetectorCfg()
+        lib().rmr_detector_cfg_default(C.byref(cfg))
+        self._path = str(engine_path).encode()
+        cfg.engine_path = self._path
+        cfg.classes = classes
+        cfg.image_width, cfg.image_height = image_size
+        cfg.max_batch_size = max_batch_size
+        cfg.opt_batch_size = opt_batch_size or 0
+        cfg.nms_thresh, cfg.conf_thresh = nms_thresh, conf_thresh
+        cfg.input_width, cfg.input_height = input_width, input_height
+        cfg.input_channels = input_channels
+        cfg.device = device
+        self.classes = classes
+        self._h = C.c_void_p()
+        check(lib().rmr_detector_create(C.byref(cfg), C.byref(self._h)))
+        self.anchors = lib().rmr_detector_anchors(self._h)
+        self.channels = lib().rmr_detector_channels(self._h)
+        self.flops_per_image = lib().rmr_detector_flops_per_image(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rmr_detector_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def detect(self, images, crops=None, cap=1024):
+        """Detector::detect<T> (detector.h:117-134): one image -> array, a list -> list."""
+        single = not isinstance(images, (list, tuple))
+        imgs = [images] if single else list(images)
+        arr, cr, keep = _images(imgs, crops)
+        n = len(imgs)
+        out = np.empty((n, cap), DET_DTYPE)
+        counts = np.zeros(n, np.int32)
+        check(lib().rmr_detector_detect(self._h, arr, cr, n, out.ctypes.data, _lib.ip(counts), cap))
+        res = [out[i, :counts[i]].copy() for i in range(n)]
+        return res[0] if single else res
+
+    def infer(self, images, crops=None):
+        """preprocess + network: the [n, 4+classes, anchors] tensor handed to postprocess."""
+        imgs = list(images)
+        arr, cr, keep = _images(imgs, crops)
+        n = len(imgs)
+        out = np.empty((n, self.channels, self.anchors), np.float32)
+        pps = (PreParam * n)()
+        check(lib().rmr_detector_infer(self._h, arr, cr, n, _lib.fp(out), pps))
+        return out, list(pps)
+
+
+class RobotDetector:
+    """radar::RobotDetector (src/detect/detector.h:171-190)."""
+
+    def __init__(self, car_engine_path, armor_engine_path, image_size, armor_classes, max_cars,
+                 opt_cars, iou_thresh=0.75, car_nms_thresh=0.65, car_conf_thresh=0.25,
+                 armor_nms_thresh=0.65, armor_conf_thresh=0.50, input_width=640,
+                 input_height=640, input_name="images", input_channels=3, opt_level=5,
+                 device=0, max_frames=1):
+        cfg = _lib.RobotDetectorCfg()
+        lib().rmr_robot_detector_cfg_default(C.byref(cfg))
+        self._paths = (str(car_engine_path).encode(), str(armor_engine_path).encode())
+        cfg.car_engine_path, cfg.armor_engine_path = self._paths
+        cfg.image_width, cfg.image_height = image_size
+        cfg.armor_classes = armor_classes
+        cfg.max_cars, cfg.opt_cars = max_cars, opt_cars
+        cfg.iou_thresh = iou_thresh
+        cfg.car_nms_thresh, cfg.car_conf_thresh = car_nms_thresh, car_conf_thresh
+        cfg.armor_nms_thresh, cfg.armor_conf_thresh = armor_nms_thresh, armor_conf_thresh
+        cfg.input_width, cfg.input_height = int(input_width), int(input_height)
+        cfg.input_channels = input_channels
+        cfg.device = device
+        cfg.max_frames = max_frames
+        self.max_cars = max_cars
+        self._h = C.c_void_p()
+        check(lib().rmr_robot_detector_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rmr_robot_detector_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def detect(self, image) -> List[Robot]:
+        """RobotDetector::detect(const cv::Mat&) (detector.cpp:413-455)"""
+        keep: list = []
+        img = _as_image(image, keep)
+        cap = self.max_cars
+        out = (_lib.Robot * cap)()
+        n = C.c_int()
+        check(lib().rmr_robot_detector_detect(self._h, C.byref(img), out, C.byref(n), cap))
+        return [Robot.from_c(out[i]) for i in range(n.value)]
+
+    def detect_batch_raw(self, images, forced_crops=None):
+        """Throughput mode; returns (ctypes Robot array [n_frames*cap], counts)."""
+        imgs = list(images)
+        arr, _, keep = _images(imgs, None)
+        n = len(imgs)
+        cap = self.max_cars
+        out = (_lib.Robot * (cap * n))()
+        counts = np.zeros(n, np.int32)
+        fc, per = None, 0
+        if forced_crops is not None:
+            fc = np.ascontiguousarray(np.asarray(forced_crops, np.int32).reshape(n, -1, 4))
+            per = fc.shape[1]
+        check(lib().rmr_robot_detector_detect_batch(self._h, arr, n, _lib.ip(fc) if fc is not None else None,
+                                                    per, out, _lib.ip(counts), cap))
+        return out, counts
+
+    def detect_batch(self, images, forced_crops=None) -> List[List[Robot]]:
+        out, counts = self.detect_batch_raw(images, forced_crops)
+        cap = self.max_cars
+        return [[Robot.from_c(out[f * cap + i]) for i in range(counts[f])]
+                for f in range(len(counts))]
+
+
+# ------------------------------------------------------------------------------- Locator
+
+class Locator:
+    """radar::Locator (src/locate/locator.h:53-98).  Clouds: [n, >=3] f32 (mm), numpy (host) or a
+    torch CUDA tensor (device)."""
+
+    DEPTH, BACKGROUND, DIFF = 0, 1, 2
+
+    def __init__(self, image_width, image_height, intrinsic, lidar_to_camera, world_to_camera,
+                 zoom_factor=0.5, queue_size=3, min_depth_diff=500.0, max_depth_diff=4000.0,
+                 cluster_tolerance=400.0, min_cluster_size=8, max_cluster_size=1000,
+                 max_distance=29300.0, device=0, max_points=262144, max_foreground=32768,
+                 max_frames=1):
+        cfg = _lib.LocatorCfg()
+        lib().rmr_locator_cfg_default(C.byref(cfg))
+        cfg.image_width, cfg.image_height = image_width, image_height
+        cfg.intrinsic[:] = np.asarray(intrinsic, np.float32).reshape(9).tolist()
+        cfg.lidar_to_camera[:] = np.asarray(lidar_to_camera, np.float32).reshape(16).tolist()
+        cfg.world_to_camera[:] = np.asarray(world_to_camera, np.float32).reshape(16).tolist()
+        cfg.zoom_factor = zoom_factor
+        cfg.queue_size = queue_size
+        cfg.min_depth_diff, cfg.max_depth_diff = min_depth_diff, max_depth_diff
+        cfg.cluster_tolerance = cluster_tolerance
+        cfg.min_cluster_size, cfg.max_cluster_size = min_cluster_size, max_cluster_size
+        cfg.max_distance = max_distance
+        cfg.device = device
+        cfg.max_points, cfg.max_foreground, cfg.max_frames = max_points, max_foreground, max_frames
+        self._h = C.c_void_p()
+        check(lib().rmr_locator_create(C.byref(cfg), C.byref(self._h)))
+        self.wz = lib().rmr_locator_width(self._h)
+        self.hz = lib().rmr_locator_height(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rmr_locator_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def update(self, cloud):
+        """Locator::update (locate.cpp:158-220); None / empty = the null / empty cloud."""
+        if cloud is None or len(cloud) == 0:
+            check(lib().rmr_locator_update(self._h, None, 0, 0, _lib.MEM_HOST))
+            return
+        if _is_device_tensor(cloud):
+            if cloud.dim() != 2 or cloud.shape[1] < 3 or cloud.element_size() != 4 or cloud.stride(1) != 1:
+                raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "device cloud must be [n, >=3] f32")
+            check(lib().rmr_locator_update(self._h, cloud.data_ptr(), cloud.shape[0],
+                                           cloud.stride(0) * 4, _lib.MEM_DEVICE))
+            return
+        a = np.ascontiguousarray(cloud, np.float32)
+        check(lib().rmr_locator_update(self._h, a.ctypes.data, a.shape[0], a.strides[0], _lib.MEM_HOST))
+
+    def cluster(self):
+        check(lib().rmr_locator_cluster(self._h))
+
+    def keep(self, frame: int):
+        check(lib().rmr_locator_keep(self._h, frame))
+
+    def _search(self, robots, frame):
+        n = len(robots)
+        if n == 0:
+            return robots
+        arr = (_lib.Robot * n)(*[r.to_c() for r in robots])
+        if frame is None:
+            check(lib().rmr_locator_search(self._h, arr, n))
+        else:
+            check(lib().rmr_locator_search_kept(self._h, frame, arr, n))
+        for r, c in zip(robots, arr):
+            if c.has_location:
+                r.location = tuple(c.location)
+        return robots
+
+    def search(self, robots: List[Robot], frame=None) -> List[Robot]:
+        """Locator::search(std::vector<Robot>&) (locate.cpp:323-326)"""
+        return self._search(robots, frame)
+
+    def search_raw(self, robots_c, n: int, frame=None):
+        if n <= 0:
+            return
+        if frame is None:
+            check(lib().rmr_locator_search(self._h, robots_c, n))
+        else:
+            check(lib().rmr_locator_search_kept(self._h, frame, robots_c, n))
+
+    # -- private members the reference's tests reach (locator_test.cpp:6-13)
+    def read_image(self, which) -> np.ndarray:
+        out = np.empty((self.hz, self.wz), np.float32)
+        check(lib().rmr_locator_read_image(self._h, which, _lib.fp(out)))
+        return out
+
+    def write_image(self, which, img):
+        img = np.ascontiguousarray(img, np.float32)
+        assert img.shape == (self.hz, self.wz)
+        check(lib().rmr_locator_write_image(self._h, which, _lib.fp(img)))
+
+    def _xf(self, which, p):
+        a = np.asarray(p, np.float32)
+        o = np.zeros(3, np.float32)
+        check(lib().rmr_locator_transform(self._h, which, _lib.fp(a), _lib.fp(o)))
+        return o
+
+    def lidar_to_world(self, p):
+        return self._xf(0, p)
+
+    def camera_to_lidar(self, p):
+        return self._xf(1, p)
+
+    def lidar_to_camera(self, p):
+        return self._xf(2, p)
+
+    def zoom(self, rect):
+        r = np.asarray(rect, np.int32)
+        o = np.zeros(4, np.int32)
+        check(lib().rmr_locator_zoom(self._h, _lib.ip(r), _lib.ip(o)))
+        return tuple(int(v) for v in o)
+
+    def foreground(self, cap=32768):
+        xyz = np.empty((cap, 3), np.float32)
+        pix = np.empty(cap, np.int32)
+        cid = np.empty(cap, np.int32)
+        n = C.c_int()
+        check(lib().rmr_locator_foreground(self._h, _lib.fp(xyz), _lib.ip(pix), _lib.ip(cid), cap, C.byref(n)))
+        m = min(n.value, cap)
+        return xyz[:m].copy(), pix[:m].copy(), cid[:m].copy()
+
+    @property
+    def num_clusters(self) -> int:
+        return lib().rmr_locator_num_clusters(self._h)
+
+
+# ------------------------------------------------------------------------------- profiling
+
+class profile:
+    """HIP-event timing of the library's own launches (on the streams they run on)."""
+
+    def __init__(self, device=0):
+        self.device = device
+
+    def __enter__(self):
+        check(lib().rmr_profile_reset(self.device))
+        check(lib().rmr_profile_enable(self.device, 1))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().rmr_profile_enable(self.device, 0))
+        return False
+
+    def read(self):
+        n = C.c_int()
+        check(lib().rmr_profile_read(self.device, None, 0, C.byref(n)))
+        arr = (_lib.KernelStat * max(n.value, 1))()
+        check(lib().rmr_profile_read(self.device, arr, n.value, C.byref(n)))
+        return {arr[i].name.decode(): {"launches": arr[i].launches, "total_ms": arr[i].total_ms,
+                                       "flops": arr[i].flops, "bytes": arr[i].bytes}
+                for i in range(n.value)}

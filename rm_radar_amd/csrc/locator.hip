@@ -1,0 +1,863 @@
+// locator.hip -- the LiDAR Locator on the GPU (src/locate/locate.cpp:37-350).
+//
+// State lives in HBM for the life of the object: the running-max background depth image,
+// a ring of the last queue_size depth images, the foreground ("diff") depth image and a
+// 64-bit key image used to make the per-pixel scatter deterministic.
+//
+//   update()   loc_scatter   one thread per point: filter, extrinsic transform, pinhole
+//                            projection, then two atomics per point -- u64 atomicMax of
+//                            ((index+1)<<32 | depth bits) => "highest point index wins"
+//                            (Q13), and int atomicMax on the background (valid because the
+//                            background is >= 0 and only d > background updates it);
+//              loc_diff      one thread per pixel: key -> ring slot, clear key, walk the
+//                            ring oldest -> newest (Q14), write the foreground image;
+//   cluster()  fg_count / fg_scan / fg_compact : row-major ordered compaction of the
+//                            non-zero foreground pixels + cameraToLidar (Q16);
+//              cc_*          Euclidean clustering = connected components of
+//                            "squared distance < tolerance^2" by lock-free union-find
+//                            (hook the larger root under the smaller), size filter,
+//                            ids ordered by (size desc, lowest member index) (Q17);
+//   search()   loc_search    one workgroup per robot over the compact foreground list:
+//                            LDS bucket histogram, first-max winner (-1 wins ties, Q18),
+//                            f64 tree-sum centroid, lidar->world, mm -> m.
+//
+// All of it is HBM/latency-bound scatter/scan work: coalesced 4-byte streams, no LDS tiling
+// of the images, and launch counts kept small.  Pixel binning and every comparison is
+// bit-exact with the oracle (same f32 op order, -ffp-contract=off); only the centroid sum
+// differs in association (tolerance 1e-3 m per BASELINE.json).
+#include "locator.h"
+
+#include <cmath>
+
+namespace rmr {
+
+constexpr int MAX_QUEUE = 16;
+struct RingOrder {
+    int n;
+    int slot[MAX_QUEUE];
+    int newest;
+};
+
+// ---- shared f32 geometry, same operation order as cv::Matx products ---------------------
+__host__ __device__ inline void mat3_vec(const float* M, const float* v, float* o) {
+    for (int i = 0; i < 3; ++i) {
+        float s = 0;
+        for (int k = 0; k < 3; ++k) s += M[i * 3 + k] * v[k];
+        o[i] = s;
+    }
+}
+
+// locate.cpp:73-81
+__host__ __device__ inline void lidar_to_camera(const LocParams& P, const float* p, float* uvd) {
+    const float v[4] = {p[0], p[1], p[2], 1.0f};
+    float c4[3];
+    for (int i = 0; i < 3; ++i) {
+        float s = 0;
+        for (int k = 0; k < 4; ++k) s += P.L2C[i * 4 + k] * v[k];
+        c4[i] = s;
+    }
+    float c[3];
+    mat3_vec(P.K, c4, c);
+    uvd[0] = c[0] * P.zoom / c[2];
+    uvd[1] = c[1] * P.zoom / c[2];
+    uvd[2] = c[2];
+}
+
+// locate.cpp:54-61 (Q16): R * ((Kinv * d) * [u/z, v/z, 1] + t)
+__host__ __device__ inline void camera_to_lidar(const LocParams& P, const float* uvd, float* out) {
+    const float cam[3] = {uvd[0] / P.zoom, uvd[1] / P.zoom, 1.0f};
+    float Ks[9];
+    for (int i = 0; i < 9; ++i) Ks[i] = P.Kinv[i] * uvd[2];
+    float q[3];
+    mat3_vec(Ks, cam, q);
+    for (int i = 0; i < 3; ++i) q[i] = q[i] + P.t[i];
+    mat3_vec(P.R, q, out);
+}
+
+// locate.cpp:37-42 with the constant product C2W * L2C formed once (same f32 result)
+__host__ __device__ inline void lidar_to_world(const LocParams& P, const float* p, float* out) {
+    const float v[4] = {p[0], p[1], p[2], 1.0f};
+    for (int i = 0; i < 3; ++i) {
+        float s = 0;
+        for (int k = 0; k < 4; ++k) s += P.L2W[i * 4 + k] * v[k];
+        out[i] = s;
+    }
+}
+
+// ---- update() ----------------------------------------------------------------------------
+
+// locate.cpp:173-193
+__global__ __launch_bounds__(256) void loc_scatter(LocParams P, const char* __restrict__ xyz,
+                                                   int n, int stride_bytes,
+                                                   unsigned long long* __restrict__ key,
+                                                   float* __restrict__ bg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* pt = (const float*)(xyz + (size_t)i * stride_bytes);
+    const float p[3] = {pt[0], pt[1], pt[2]};
+    if (p[0] == 0 && p[1] == 0 && p[2] == 0) return;  // locate.cpp:176
+    if (p[0] > P.max_distance) return;                // locate.cpp:179
+    float uvd[3];
+    lidar_to_camera(P, p, uvd);
+    const float u = uvd[0], v = uvd[1], d = uvd[2];
+    // locate.cpp:184-187 with Q15: u == Wz / v == Hz (and NaN) are out of range here
+    if (!(u >= 0 && u < (float)P.wz && v >= 0 && v < (float)P.hz)) return;
+    const size_t idx = (size_t)(int)v * P.wz + (int)u;
+    // background = running max (locate.cpp:188-191); it never goes below +0, so only
+    // positive depths can raise it and positive floats order like their int bits
+    if (d > 0) atomicMax((int*)&bg[idx], __float_as_int(d));
+    // depth = last writer in point order (locate.cpp:192, Q13)
+    const unsigned long long k =
+        ((unsigned long long)(unsigned)(i + 1) << 32) | (unsigned)__float_as_uint(d);
+    atomicMax(&key[idx], k);
+}
+
+// locate.cpp:195-219
+__global__ __launch_bounds__(256) void loc_diff(LocParams P, RingOrder order,
+                                                unsigned long long* __restrict__ key,
+                                                const float* __restrict__ bg,
+                                                float* __restrict__ ring,
+                                                float* __restrict__ diff, size_t npx) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npx) return;
+    const unsigned long long k = key[p];
+    const float cur = k ? __uint_as_float((unsigned)(k & 0xffffffffull)) : 0.0f;
+    if (k) key[p] = 0;
+    ring[(size_t)order.newest * npx + p] = cur;
+    const float b = bg[p];
+    float out = 0.0f;
+    for (int q = 0; q < order.n; ++q) {
+        const int s = order.slot[q];
+        const float value = (s == order.newest) ? cur : ring[(size_t)s * npx + p];
+        if (value == 0) continue;
+        const float df = b - value;
+        if (df >= P.min_diff && df <= P.max_diff) out = value;
+    }
+    diff[p] = out;
+}
+
+// ---- cluster(): ordered compaction ---------------------------------------------------------
+
+constexpr int FG_PX_PER_BLOCK = 1024;  // 256 threads x 4 consecutive pixels
+
+__global__ __launch_bounds__(256) void fg_count(const float* __restrict__ diff, size_t npx,
+                                                int* __restrict__ blk_count) {
+    __shared__ int wsum[4];
+    const size_t base = (size_t)blockIdx.x * FG_PX_PER_BLOCK + (size_t)threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (base + j < npx && diff[base + j] != 0) ++c;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// counters: [0] n_fg (clamped) [1] overflow flag [2] n_valid clusters
+__global__ __launch_bounds__(1024) void fg_scan(const int* __restrict__ blk_count, int nblk,
+                                                int* __restrict__ blk_offset, int max_fg,
+                                                int* __restrict__ counters,
+                                                int* __restrict__ slot_n_fg) {
+    __shared__ int wtot[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? blk_count[i] : 0;
+        int incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wtot[wid] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wid; ++w) before += wtot[w];
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += wtot[w];
+        if (i < nblk) blk_offset[i] = carry + before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int n = carry;
+        counters[1] = n > max_fg ? 1 : 0;
+        counters[0] = n > max_fg ? max_fg : n;
+        counters[2] = 0;
+        *slot_n_fg = counters[0];
+    }
+}
+
+// locate.cpp:237-250
+__global__ __launch_bounds__(256) void fg_compact(LocParams P, const float* __restrict__ diff,
+                                                  size_t npx, const int* __restrict__ blk_offset,
+                                                  int max_fg, int* __restrict__ fg_pixel,
+                                                  float* __restrict__ fg_xyz) {
+    __shared__ int wtot[4];
+    const size_t base = (size_t)blockIdx.x * FG_PX_PER_BLOCK + (size_t)threadIdx.x * 4;
+    float val[4];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        val[j] = (base + j < npx) ? diff[base + j] : 0.0f;
+        if (val[j] != 0) ++c;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wtot[wid] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wid; ++w) before += wtot[w];
+    int dst = blk_offset[blockIdx.x] + before + incl - c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (val[j] != 0) {
+            if (dst < max_fg) {
+                const size_t p = base + j;
+                const int v = (int)(p / P.wz), u = (int)(p % P.wz);
+                const float uvd[3] = {(float)u, (float)v, val[j]};
+                float o[3];
+                camera_to_lidar(P, uvd, o);
+                fg_pixel[dst] = (int)p;
+                fg_xyz[dst * 3 + 0] = o[0];
+                fg_xyz[dst * 3 + 1] = o[1];
+                fg_xyz[dst * 3 + 2] = o[2];
+            }
+            ++dst;
+        }
+    }
+}
+
+// ---- cluster(): connected components ---------------------------------------------------------
+
+__device__ __forceinline__ int ld_parent(const int* parent, int i) {
+    return __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int find_root(const int* parent, int x) {
+    int p = ld_parent(parent, x);
+    while (p != x) {
+        x = p;
+        p = ld_parent(parent, x);
+    }
+    return x;
+}
+
+// Hook the larger root under the smaller: every tree's root is its lowest member index.
+__device__ __forceinline__ void unite(int* parent, int a, int b) {
+    for (;;) {
+        a = find_root(parent, a);
+        b = find_root(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(parent + a, a, b) == a) return;
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_init(const int* __restrict__ counters,
+                                               int* __restrict__ parent, int* __restrict__ csize,
+                                               int* __restrict__ root_id) {
+    const int n = counters[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        parent[i] = i;
+        csize[i] = 0;
+        root_id[i] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_pairs(const int* __restrict__ counters,
+                                                const float* __restrict__ xyz, float tol2,
+                                                int* __restrict__ parent) {
+    __shared__ float tx[256], ty[256], tz[256];
+    const int n = counters[0];
+    const int blk_base = blockIdx.x * 256;
+    if (blk_base >= n) return;
+    const int i = blk_base + threadIdx.x;
+    float ax = 0, ay = 0, az = 0;
+    if (i < n) {
+        ax = xyz[i * 3 + 0];
+        ay = xyz[i * 3 + 1];
+        az = xyz[i * 3 + 2];
+    }
+    const int jmax = min(n, blk_base + 256);  // pairs j < i only
+    for (int tile = 0; tile < jmax; tile += 256) {
+        const int j = tile + threadIdx.x;
+        if (j < n) {
+            tx[threadIdx.x] = xyz[j * 3 + 0];
+            ty[threadIdx.x] = xyz[j * 3 + 1];
+            tz[threadIdx.x] = xyz[j * 3 + 2];
+        }
+        __syncthreads();
+        if (i < n) {
+            const int m = min(256, i - tile);  // j < i
+            for (int q = 0; q < m; ++q) {
+                const float dx = tx[q] - ax, dy = ty[q] - ay, dz = tz[q] - az;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < tol2) unite(parent, i, tile + q);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_flatten(const int* __restrict__ counters,
+                                                  int* __restrict__ parent,
+                                                  int* __restrict__ csize) {
+    const int n = counters[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = find_root(parent, i);
+    atomicAdd(csize + r, 1);
+    // roots keep parent[r] == r; writing a non-root's parent is race-free here because
+    // find_root of any other thread still terminates at the same root
+    if (r != i) __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void cc_valid(int* __restrict__ counters,
+                                                const int* __restrict__ parent,
+                                                const int* __restrict__ csize, int min_size,
+                                                int max_size, int* __restrict__ vroot,
+                                                int* __restrict__ vsize) {
+    const int n = counters[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (parent[i] != i) return;
+    const int s = csize[i];
+    if (s >= min_size && s <= max_size) {
+        const int k = atomicAdd(counters + 2, 1);
+        vroot[k] = i;
+        vsize[k] = s;
+    }
+}
+
+// cluster id = rank under (size descending, root ascending)
+__global__ __launch_bounds__(256) void cc_rank(const int* __restrict__ counters,
+                                               const int* __restrict__ vroot,
+                                               const int* __restrict__ vsize,
+                                               int* __restrict__ root_id) {
+    const int nv = counters[2];
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= nv) return;
+    const int ra = vroot[a], sa = vsize[a];
+    int rank = 0;
+    for (int b = 0; b < nv; ++b) {
+        const int sb = vsize[b], rb = vroot[b];
+        if (sb > sa || (sb == sa && rb < ra)) ++rank;
+    }
+    root_id[ra] = rank;
+}
+
+__global__ __launch_bounds__(256) void cc_assign(const int* __restrict__ counters,
+                                                 const int* __restrict__ parent,
+                                                 const int* __restrict__ root_id,
+                                                 int* __restrict__ fg_cluster,
+                                                 int* __restrict__ slot_n_clusters) {
+    const int n = counters[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *slot_n_clusters = counters[2];
+    if (i >= n) return;
+    fg_cluster[i] = root_id[parent[i]];
+}
+
+__global__ __launch_bounds__(256) void slot_copy(const int* __restrict__ s_nfg,
+                                                 const int* __restrict__ s_ncl,
+                                                 const int* __restrict__ s_pix,
+                                                 const float* __restrict__ s_xyz,
+                                                 const int* __restrict__ s_cl,
+                                                 int* __restrict__ d_nfg, int* __restrict__ d_ncl,
+                                                 int* __restrict__ d_pix, float* __restrict__ d_xyz,
+                                                 int* __restrict__ d_cl) {
+    const int n = *s_nfg;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        *d_nfg = n;
+        *d_ncl = *s_ncl;
+    }
+    if (i >= n) return;
+    d_pix[i] = s_pix[i];
+    d_cl[i] = s_cl[i];
+    d_xyz[i * 3 + 0] = s_xyz[i * 3 + 0];
+    d_xyz[i * 3 + 1] = s_xyz[i * 3 + 1];
+    d_xyz[i * 3 + 2] = s_xyz[i * 3 + 2];
+}
+
+// ---- search() ------------------------------------------------------------------------------
+
+// locate.cpp:276-311.  rects: zoomed (x,y,w,h) per robot; out: {located, x, y, z} (metres).
+__global__ __launch_bounds__(256) void loc_search(LocParams P, const int* __restrict__ n_fg_p,
+                                                  const int* __restrict__ n_cl_p,
+                                                  const int* __restrict__ fg_pixel,
+                                                  const float* __restrict__ fg_xyz,
+                                                  const int* __restrict__ fg_cluster,
+                                                  const int* __restrict__ rects,
+                                                  float* __restrict__ out, int max_buckets) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    int* cnt = smem;  // [max_buckets] bucket b = cluster id b-1
+    __shared__ int red_cnt[4], red_key[4];
+    __shared__ double red_s[4][3];
+    __shared__ int win_key, win_cnt;
+
+    const int n = *n_fg_p;
+    const int nb = min(*n_cl_p + 1, max_buckets);
+    const int rx = rects[blockIdx.x * 4 + 0], ry = rects[blockIdx.x * 4 + 1];
+    const int rw = rects[blockIdx.x * 4 + 2], rh = rects[blockIdx.x * 4 + 3];
+    for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int p = fg_pixel[i];
+        const int v = p / P.wz, u = p % P.wz;
+        if (u >= rx && u < rx + rw && v >= ry && v < ry + rh) atomicAdd(&cnt[fg_cluster[i] + 1], 1);
+    }
+    __syncthreads();
+    // first max in ascending key: larger count wins, equal counts -> smaller key
+    int bc = 0, bk = 0x7fffffff;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        const int c = cnt[b];
+        if (c > bc || (c == bc && c > 0 && b < bk)) {
+            bc = c;
+            bk = b;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const int oc = __shfl_down(bc, o), ok = __shfl_down(bk, o);
+        if (oc > bc || (oc == bc && ok < bk)) {
+            bc = oc;
+            bk = ok;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red_cnt[threadIdx.x >> 6] = bc;
+        red_key[threadIdx.x >> 6] = bk;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = red_cnt[0], k = red_key[0];
+        for (int w = 1; w < 4; ++w)
+            if (red_cnt[w] > c || (red_cnt[w] == c && red_key[w] < k)) {
+                c = red_cnt[w];
+                k = red_key[w];
+            }
+        win_cnt = c;
+        win_key = k;
+    }
+    __syncthreads();
+    const int wc = win_cnt, wk = win_key;
+    if (wc == 0) {
+        if (threadIdx.x == 0) {
+            out[blockIdx.x * 4 + 0] = 0;
+            out[blockIdx.x * 4 + 1] = out[blockIdx.x * 4 + 2] = out[blockIdx.x * 4 + 3] = 0;
+        }
+        return;
+    }
+    double sx = 0, sy = 0, sz = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int p = fg_pixel[i];
+        const int v = p / P.wz, u = p % P.wz;
+        if (u >= rx && u < rx + rw && v >= ry && v < ry + rh && fg_cluster[i] + 1 == wk) {
+            sx += (double)fg_xyz[i * 3 + 0];
+            sy += (double)fg_xyz[i * 3 + 1];
+            sz += (double)fg_xyz[i * 3 + 2];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_down(sx, o);
+        sy += __shfl_down(sy, o);
+        sz += __shfl_down(sz, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red_s[threadIdx.x >> 6][0] = sx;
+        red_s[threadIdx.x >> 6][1] = sy;
+        red_s[threadIdx.x >> 6][2] = sz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s[3];
+        for (int k = 0; k < 3; ++k) s[k] = ((red_s[0][k] + red_s[1][k]) + red_s[2][k]) + red_s[3][k];
+        const float loc[3] = {(float)(s[0] / (double)wc), (float)(s[1] / (double)wc),
+                              (float)(s[2] / (double)wc)};
+        float w[3];
+        lidar_to_world(P, loc, w);
+        out[blockIdx.x * 4 + 0] = 1.0f;
+        for (int k = 0; k < 3; ++k) out[blockIdx.x * 4 + 1 + k] = (float)((double)w[k] * 1e-3);
+    }
+}
+
+// ---- host: OpenCV-compatible inverses [OpenCV behaviour] --------------------------------------
+
+// cv::Matx33f::inv(): closed-form adjugate in f32
+bool inv3x3_f32(const float a[9], float b[9]) {
+    auto A = [&](int i, int j) { return a[i * 3 + j]; };
+    float d = A(0, 0) * (A(1, 1) * A(2, 2) - A(2, 1) * A(1, 2)) -
+              A(0, 1) * (A(1, 0) * A(2, 2) - A(2, 0) * A(1, 2)) +
+              A(0, 2) * (A(1, 0) * A(2, 1) - A(2, 0) * A(1, 1));
+    if (d == 0) {
+        std::memset(b, 0, 9 * sizeof(float));
+        return false;
+    }
+    d = 1 / d;
+    b[0] = (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) * d;
+    b[1] = (A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2)) * d;
+    b[2] = (A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1)) * d;
+    b[3] = (A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2)) * d;
+    b[4] = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) * d;
+    b[5] = (A(0, 2) * A(1, 0) - A(0, 0) * A(1, 2)) * d;
+    b[6] = (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0)) * d;
+    b[7] = (A(0, 1) * A(2, 0) - A(0, 0) * A(2, 1)) * d;
+    b[8] = (A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0)) * d;
+    return true;
+}
+
+// cv::Matx44f::inv(): LU with partial pivoting on [A | I], f32
+bool inv4x4_f32(const float a[16], float out[16]) {
+    float A[4][4], B[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            A[i][j] = a[i * 4 + j];
+            B[i][j] = i == j ? 1.0f : 0.0f;
+        }
+    for (int i = 0; i < 4; ++i) {
+        int k = i;
+        for (int j = i + 1; j < 4; ++j)
+            if (std::fabs(A[j][i]) > std::fabs(A[k][i])) k = j;
+        if (std::fabs(A[k][i]) < 1.1920929e-06f) {
+            std::memset(out, 0, 16 * sizeof(float));
+            return false;
+        }
+        if (k != i) {
+            for (int j = i; j < 4; ++j) std::swap(A[i][j], A[k][j]);
+            for (int j = 0; j < 4; ++j) std::swap(B[i][j], B[k][j]);
+        }
+        const float d = -1 / A[i][i];
+        for (int j = i + 1; j < 4; ++j) {
+            const float alpha = A[j][i] * d;
+            for (int q = i + 1; q < 4; ++q) A[j][q] += alpha * A[i][q];
+            for (int q = 0; q < 4; ++q) B[j][q] += alpha * B[i][q];
+        }
+    }
+    for (int i = 3; i >= 0; --i)
+        for (int j = 0; j < 4; ++j) {
+            float s = B[i][j];
+            for (int k = i + 1; k < 4; ++k) s -= A[i][k] * B[k][j];
+            B[i][j] = s / A[i][i];
+        }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[i * 4 + j] = B[i][j];
+    return true;
+}
+
+// ---- host: Locator ----------------------------------------------------------------------------
+
+static inline int cv_round(float v) { return (int)lrintf(v); }  // saturate_cast<int>(float)
+
+// locate.cpp:112-146
+Locator::Locator(const rmr_locator_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg.device)) {
+    if (cfg.image_width <= 0 || cfg.image_height <= 0)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator: image size must be positive");
+    if (cfg.queue_size < 1 || cfg.queue_size > MAX_QUEUE)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator: queue_size must be in 1..%d", MAX_QUEUE);
+    if (cfg_.max_points <= 0) cfg_.max_points = 262144;
+    if (cfg_.max_foreground <= 0) cfg_.max_foreground = 32768;
+    if (cfg_.max_frames <= 0) cfg_.max_frames = 1;
+    prm_.zoom = cfg.zoom_factor;
+    prm_.wz = (int)((float)cfg.image_width * cfg.zoom_factor);
+    prm_.hz = (int)((float)cfg.image_height * cfg.zoom_factor);
+    if (prm_.wz <= 0 || prm_.hz <= 0) fail(RMR_ERR_INVALID_ARGUMENT, "Locator: zoomed image is empty");
+    std::memcpy(prm_.K, cfg.intrinsic, sizeof(prm_.K));
+    std::memcpy(prm_.L2C, cfg.lidar_to_camera, sizeof(prm_.L2C));
+    inv3x3_f32(prm_.K, prm_.Kinv);
+    float c2l[16], c2w[16];
+    inv4x4_f32(prm_.L2C, c2l);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) prm_.R[i * 3 + j] = c2l[i * 4 + j];
+        prm_.t[i] = c2l[i * 4 + 3];
+    }
+    inv4x4_f32(cfg.world_to_camera, c2w);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0;
+            for (int k = 0; k < 4; ++k) s += c2w[i * 4 + k] * prm_.L2C[k * 4 + j];
+            prm_.L2W[i * 4 + j] = s;
+        }
+    prm_.min_diff = cfg.min_depth_diff;
+    prm_.max_diff = cfg.max_depth_diff;
+    prm_.max_distance = cfg.max_distance;
+    prm_.tol2 = cfg.cluster_tolerance * cfg.cluster_tolerance;
+    prm_.min_cluster = cfg.min_cluster_size;
+    prm_.max_cluster = cfg.max_cluster_size;
+
+    npx_ = (size_t)prm_.wz * prm_.hz;
+    const int mf = cfg_.max_foreground;
+    max_clusters_ = mf / (cfg.min_cluster_size > 1 ? cfg.min_cluster_size : 1);
+    if ((size_t)(max_clusters_ + 1) * sizeof(int) > 150 * 1024)
+        fail(RMR_ERR_INVALID_ARGUMENT,
+             "Locator: max_foreground/min_cluster_size = %d buckets exceed the LDS histogram",
+             max_clusters_);
+
+    RMR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    key_.alloc(npx_);
+    bg_.alloc(npx_);
+    diff_.alloc(npx_);
+    ring_.alloc(npx_ * cfg.queue_size);
+    RMR_HIP(hipMemsetAsync(key_.p, 0, npx_ * sizeof(unsigned long long), stream_));
+    RMR_HIP(hipMemsetAsync(bg_.p, 0, npx_ * sizeof(float), stream_));  // Q12: zero-initialised
+    RMR_HIP(hipMemsetAsync(diff_.p, 0, npx_ * sizeof(float), stream_));
+    RMR_HIP(hipMemsetAsync(ring_.p, 0, npx_ * cfg.queue_size * sizeof(float), stream_));
+    cloud_.alloc((size_t)cfg_.max_points * 4);
+    cloud_pin_.alloc((size_t)cfg_.max_points * 4);
+
+    const int nblk = (int)((npx_ + FG_PX_PER_BLOCK - 1) / FG_PX_PER_BLOCK);
+    blk_count_.alloc(nblk);
+    blk_offset_.alloc(nblk);
+    parent_.alloc(mf);
+    csize_.alloc(mf);
+    vroot_.alloc(mf);
+    vsize_.alloc(mf);
+    root_id_.alloc(mf);
+    counters_.alloc(4);
+    RMR_HIP(hipMemsetAsync(counters_.p, 0, 4 * sizeof(int), stream_));
+
+    const int nslots = 1 + cfg_.max_frames;
+    slot_ints_.alloc((size_t)nslots * (2 + 2 * (size_t)mf));
+    slot_floats_.alloc((size_t)nslots * 3 * (size_t)mf);
+    RMR_HIP(hipMemsetAsync(slot_ints_.p, 0, slot_ints_.n * sizeof(int), stream_));
+    for (int s = 0; s < nslots; ++s) {
+        FrameSlot f;
+        int* base = slot_ints_.p + (size_t)s * (2 + 2 * (size_t)mf);
+        f.n_fg = base;
+        f.n_clusters = base + 1;
+        f.fg_pixel = base + 2;
+        f.fg_cluster = base + 2 + mf;
+        f.fg_xyz = slot_floats_.p + (size_t)s * 3 * mf;
+        slots_.push_back(f);
+    }
+    rects_dev_.alloc(4 * 256);
+    loc_dev_.alloc(4 * 256);
+    rects_pin_.alloc(4 * 256);
+    loc_pin_.alloc(4 * 256);
+    RMR_HIP(hipStreamSynchronize(stream_));
+}
+
+Locator::~Locator() {
+    if (stream_) {
+        (void)hipStreamSynchronize(stream_);
+        (void)hipStreamDestroy(stream_);
+    }
+}
+
+// locate.cpp:158-220
+void Locator::update(const float* xyz, int n, int stride_bytes, int mem) {
+    ctx_.use();
+    if (!xyz || n <= 0) {
+        // locate.cpp:160-171: depth and diff cleared, nothing queued
+        RMR_HIP(hipMemsetAsync(diff_.p, 0, npx_ * sizeof(float), stream_));
+        return;
+    }
+    if (stride_bytes < 12 || (stride_bytes & 3))
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator::update: stride_bytes must be a multiple of 4, >= 12");
+    if (n > cfg_.max_points) fail(RMR_ERR_CAPACITY, "Locator::update: %d points exceed max_points=%d", n, cfg_.max_points);
+    const char* dev_xyz;
+    if (mem == RMR_MEM_DEVICE) {
+        dev_xyz = (const char*)xyz;
+    } else {
+        const size_t bytes = (size_t)n * stride_bytes;
+        if (bytes > cloud_.n * sizeof(float)) {
+            cloud_.alloc(bytes / 4 + 4);
+            cloud_pin_.alloc(bytes / 4 + 4);
+        }
+        // the pinned staging buffer is reused: wait for the previous frame's copy
+        RMR_HIP(hipStreamSynchronize(stream_));
+        std::memcpy(cloud_pin_.p, xyz, bytes);
+        RMR_HIP(hipMemcpyAsync(cloud_.p, cloud_pin_.p, bytes, hipMemcpyHostToDevice, stream_));
+        dev_xyz = (const char*)cloud_.p;
+    }
+    {
+        ProfScope ps(ctx_.prof, stream_, "loc_scatter", 0, (double)n * 16);
+        loc_scatter<<<(n + 255) / 256, 256, 0, stream_>>>(prm_, dev_xyz, n, stride_bytes, key_.p, bg_.p);
+        RMR_HIP(hipGetLastError());
+    }
+    // locate.cpp:195-198: push_back, pop_front when over queue_size
+    const int Q = cfg_.queue_size;
+    int newest;
+    if (ring_len_ < Q) {
+        newest = (ring_head_ + ring_len_) % Q;
+        ++ring_len_;
+    } else {
+        newest = ring_head_;
+        ring_head_ = (ring_head_ + 1) % Q;
+    }
+    RingOrder order{};
+    order.n = ring_len_;
+    order.newest = newest;
+    for (int i = 0; i < ring_len_; ++i) order.slot[i] = (ring_head_ + i) % Q;
+    {
+        ProfScope ps(ctx_.prof, stream_, "loc_diff", 0, (double)npx_ * (8 + 4 * (ring_len_ + 2)));
+        loc_diff<<<(unsigned)((npx_ + 255) / 256), 256, 0, stream_>>>(prm_, order, key_.p, bg_.p, ring_.p, diff_.p, npx_);
+        RMR_HIP(hipGetLastError());
+    }
+}
+
+// locate.cpp:231-264
+void Locator::cluster() {
+    ctx_.use();
+    const int mf = cfg_.max_foreground;
+    const int nblk = (int)((npx_ + FG_PX_PER_BLOCK - 1) / FG_PX_PER_BLOCK);
+    const int gfg = (mf + 255) / 256;
+    FrameSlot& cur = slots_[0];
+    ProfScope ps(ctx_.prof, stream_, "loc_cluster", 0, (double)npx_ * 8);
+    fg_count<<<nblk, 256, 0, stream_>>>(diff_.p, npx_, blk_count_.p);
+    fg_scan<<<1, 1024, 0, stream_>>>(blk_count_.p, nblk, blk_offset_.p, mf, counters_.p, cur.n_fg);
+    fg_compact<<<nblk, 256, 0, stream_>>>(prm_, diff_.p, npx_, blk_offset_.p, mf, cur.fg_pixel, cur.fg_xyz);
+    cc_init<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p, root_id_.p);
+    cc_pairs<<<gfg, 256, 0, stream_>>>(counters_.p, cur.fg_xyz, prm_.tol2, parent_.p);
+    cc_flatten<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p);
+    cc_valid<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p, prm_.min_cluster, prm_.max_cluster, vroot_.p, vsize_.p);
+    cc_rank<<<gfg, 256, 0, stream_>>>(counters_.p, vroot_.p, vsize_.p, root_id_.p);
+    cc_assign<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, root_id_.p, cur.fg_cluster, cur.n_clusters);
+    RMR_HIP(hipGetLastError());
+}
+
+void Locator::keep(int frame) {
+    ctx_.use();
+    if (frame < 0 || frame >= cfg_.max_frames)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator::keep: frame %d out of range (max_frames=%d)", frame, cfg_.max_frames);
+    const FrameSlot& s = slots_[0];
+    const FrameSlot& d = slots_[1 + frame];
+    slot_copy<<<(cfg_.max_foreground + 255) / 256, 256, 0, stream_>>>(
+        s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz, s.fg_cluster, d.n_fg, d.n_clusters, d.fg_pixel, d.fg_xyz, d.fg_cluster);
+    RMR_HIP(hipGetLastError());
+}
+
+// locate.cpp:337-350 (Q19)
+void Locator::zoom(const int rect[4], int out[4]) const {
+    const float z = prm_.zoom;
+    const float center_x = (float)rect[0] * z + (float)rect[2] * z * 0.5f;
+    const float center_y = (float)rect[1] * z + (float)rect[3] * z * 0.5f;
+    const int ret_width = (int)((float)rect[2] * z);
+    const int ret_height = (int)((float)rect[3] * z);
+    const int ret_x = (int)(center_x - (float)ret_width * 0.5f);
+    const int ret_y = (int)(center_y - (float)ret_height * 0.5f);
+    const int x1 = std::max(ret_x, 0), y1 = std::max(ret_y, 0);
+    const int x2 = std::min(ret_x + ret_width, prm_.wz), y2 = std::min(ret_y + ret_height, prm_.hz);
+    if (x2 - x1 <= 0 || y2 - y1 <= 0) {
+        out[0] = out[1] = out[2] = out[3] = 0;
+        return;
+    }
+    out[0] = x1;
+    out[1] = y1;
+    out[2] = x2 - x1;
+    out[3] = y2 - y1;
+}
+
+// locate.cpp:323-326 over locate.cpp:276-311
+void Locator::search(rmr_robot* robots, int n, int slot) {
+    ctx_.use();
+    if (n <= 0) return;
+    if (slot < -1 || slot >= cfg_.max_frames)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator::search: frame %d out of range", slot);
+    const FrameSlot& f = slots_[slot + 1];
+    rects_pin_.ensure((size_t)4 * n);
+    loc_pin_.ensure((size_t)4 * n);
+    rects_dev_.ensure((size_t)4 * n);
+    loc_dev_.ensure((size_t)4 * n);
+    for (int i = 0; i < n; ++i) {
+        // Robot::rect(): Rect2f -> Rect rounds half to even (robot.h:111)
+        const int ri[4] = {cv_round(robots[i].rect[0]), cv_round(robots[i].rect[1]),
+                           cv_round(robots[i].rect[2]), cv_round(robots[i].rect[3])};
+        zoom(ri, rects_pin_.p + 4 * i);
+    }
+    RMR_HIP(hipMemcpyAsync(rects_dev_.p, rects_pin_.p, sizeof(int) * 4 * n, hipMemcpyHostToDevice, stream_));
+    {
+        ProfScope ps(ctx_.prof, stream_, "loc_search", 0, 0);
+        const int nbuckets = max_clusters_ + 1;
+        loc_search<<<n, 256, nbuckets * sizeof(int), stream_>>>(prm_, f.n_fg, f.n_clusters, f.fg_pixel, f.fg_xyz,
+                                                                f.fg_cluster, rects_dev_.p, loc_dev_.p, nbuckets);
+        RMR_HIP(hipGetLastError());
+    }
+    RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, stream_));
+    int flags[2] = {0, 0};
+    RMR_HIP(hipMemcpyAsync(flags, counters_.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < n; ++i) {
+        const float* o = loc_pin_.p + 4 * i;
+        if (o[0] != 0) {
+            robots[i].has_location = 1;
+            robots[i].location[0] = o[1];
+            robots[i].location[1] = o[2];
+            robots[i].location[2] = o[3];
+        }
+    }
+    if (flags[0]) fail(RMR_ERR_CAPACITY, "Locator: foreground exceeded max_foreground=%d points", cfg_.max_foreground);
+}
+
+float* Locator::image_ptr(int which) {
+    switch (which) {
+        case RMR_LOC_DEPTH: {
+            const int Q = cfg_.queue_size;
+            const int newest = ring_len_ ? (ring_head_ + ring_len_ - 1) % Q : 0;
+            return ring_.p + (size_t)newest * npx_;
+        }
+        case RMR_LOC_BACKGROUND: return bg_.p;
+        case RMR_LOC_DIFF: return diff_.p;
+    }
+    fail(RMR_ERR_INVALID_ARGUMENT, "Locator: unknown image id %d", which);
+}
+
+void Locator::read_image(int which, float* host_out) {
+    ctx_.use();
+    RMR_HIP(hipMemcpyAsync(host_out, image_ptr(which), npx_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+}
+
+void Locator::write_image(int which, const float* host_in) {
+    ctx_.use();
+    RMR_HIP(hipMemcpyAsync(image_ptr(which), host_in, npx_ * sizeof(float), hipMemcpyHostToDevice, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+}
+
+void Locator::transform(int which, const float in[3], float out[3]) const {
+    switch (which) {
+        case RMR_XF_LIDAR_TO_WORLD: lidar_to_world(prm_, in, out); return;
+        case RMR_XF_CAMERA_TO_LIDAR: camera_to_lidar(prm_, in, out); return;
+        case RMR_XF_LIDAR_TO_CAMERA: lidar_to_camera(prm_, in, out); return;
+    }
+    fail(RMR_ERR_INVALID_ARGUMENT, "Locator: unknown transform id %d", which);
+}
+
+void Locator::foreground(float* xyz, int* pixel, int* cluster, int cap, int* n) {
+    ctx_.use();
+    const FrameSlot& f = slots_[0];
+    int hdr[2] = {0, 0};
+    RMR_HIP(hipMemcpyAsync(hdr, f.n_fg, sizeof(int) * 2, hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+    const int m = std::min(hdr[0], cap);
+    *n = hdr[0];
+    if (m > 0) {
+        if (xyz) RMR_HIP(hipMemcpyAsync(xyz, f.fg_xyz, sizeof(float) * 3 * m, hipMemcpyDeviceToHost, stream_));
+        if (pixel) RMR_HIP(hipMemcpyAsync(pixel, f.fg_pixel, sizeof(int) * m, hipMemcpyDeviceToHost, stream_));
+        if (cluster) RMR_HIP(hipMemcpyAsync(cluster, f.fg_cluster, sizeof(int) * m, hipMemcpyDeviceToHost, stream_));
+        RMR_HIP(hipStreamSynchronize(stream_));
+    }
+}
+
+int Locator::num_clusters() {
+    ctx_.use();
+    int v = 0;
+    RMR_HIP(hipMemcpyAsync(&v, slots_[0].n_clusters, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+    return v;
+}
+
+}  // namespace rmr

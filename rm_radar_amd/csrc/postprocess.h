@@ -1,0 +1,17 @@
+// postprocess.h -- fused decode + NMS + restore launcher.
+#pragma once
+#include "common.h"
+
+namespace rmr {
+
+// net_out: DEVICE [n][channels][anchors] f32.  pps_dev: DEVICE rmr_preparam[n].
+// scratch: DEVICE, postprocess_scratch_bytes(n, anchors).  out_dev: DEVICE [n][cap].
+void launch_postprocess(DeviceCtx& ctx, hipStream_t stream, const float* net_out, int n,
+                        int channels, int anchors, int classes, float nms_thresh,
+                        float conf_thresh, const rmr_preparam* pps_dev, void* scratch,
+                        rmr_detection* out_dev, int* counts_dev, int cap);
+size_t postprocess_scratch_bytes(int n, int anchors);
+
+void launch_transpose(hipStream_t stream, const float* src, float* dst, int rows, int cols);
+
+}  // namespace rmr

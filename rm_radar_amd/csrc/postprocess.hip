@@ -1,0 +1,209 @@
+// postprocess.hip -- one fused launch for the reference's transposeKernel + decodeKernel +
+// NMSKernel + host NaN filter + restoreDetection (src/detect/detector.cu:185-360, 522-582;
+// src/detect/detector.cpp:258-268), one 1024-thread workgroup per image.
+//
+//   pass 1  read the network output [C][A] directly (coalesced over A -- the transpose is a
+//           pure layout change, Q6), argmax over classes (first max, Q7), keep rows with
+//           !(conf < thresh), compact them IN ANCHOR ORDER with wave ballots + an LDS scan;
+//   pass 2  "any-higher" NMS (Q9) over the k survivors only (k^2 instead of the reference's
+//           8400^2 pair tests), candidates staged through LDS tiles;
+//   pass 3  ordered compaction of the kept rows, restore to source-image pixels, write.
+//
+// Bit-exact against the oracle: same f32 operation order, IEEE division, no contraction.
+#include "postprocess.h"
+
+namespace rmr {
+
+constexpr int PP_THREADS = 1024;
+constexpr int PP_WAVES = PP_THREADS / 64;
+
+struct Cand {
+    float x, y, w, h, label, conf;
+};
+
+// detector.cu:271-293
+__device__ __forceinline__ float iou_xywh(float x1, float y1, float w1, float h1, float x2,
+                                          float y2, float w2, float h2) {
+    const float x_left = fmaxf(x1, x2);
+    const float y_top = fmaxf(y1, y2);
+    const float x_right = fminf(x1 + w1, x2 + w2);
+    const float y_bottom = fminf(y1 + h1, y2 + h2);
+    if (x_right < x_left || y_bottom < y_top) return 0.0f;
+    const float iw = x_right - x_left;
+    const float ih = y_bottom - y_top;
+    const float inter = iw * ih;
+    const float area1 = w1 * h1;
+    const float area2 = w2 * h2;
+    const float uni = area1 + area2 - inter;
+    return inter / uni;
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+    return v < lo ? lo : (hi < v ? hi : v);
+}
+
+// Block-wide ordered rank of `flag` among threads with a lower id; returns the block total
+// through `total`.  Two barriers; wave_tot is LDS scratch of PP_WAVES ints.
+__device__ __forceinline__ int block_rank(bool flag, int* wave_tot, int& total) {
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int lane_rank = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wid] = __popcll(bal);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < PP_WAVES; ++w) {
+        const int t = wave_tot[w];
+        before += (w < wid) ? t : 0;
+        all += t;
+    }
+    __syncthreads();
+    total = all;
+    return before + lane_rank;
+}
+
+__global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
+    const float* __restrict__ net_out, int channels, int anchors, int classes, float nms_thresh,
+    float conf_thresh, const rmr_preparam* __restrict__ pps, Cand* __restrict__ scratch,
+    rmr_detection* __restrict__ out, int* __restrict__ counts, int cap) {
+    __shared__ int wave_tot[PP_WAVES];
+    __shared__ float t_x[PP_THREADS], t_y[PP_THREADS], t_w[PP_THREADS], t_h[PP_THREADS],
+        t_l[PP_THREADS], t_c[PP_THREADS];
+
+    const int img = blockIdx.x;
+    const float* src = net_out + (size_t)img * channels * anchors;
+    Cand* cand = scratch + (size_t)img * anchors;
+    const int tid = threadIdx.x;
+
+    // ---- pass 1: decode + threshold + ordered compaction ----
+    int k = 0;
+    for (int base = 0; base < anchors; base += PP_THREADS) {
+        const int a = base + tid;
+        bool pass = false;
+        Cand c{};
+        if (a < anchors) {
+            const float cx = src[a];
+            const float cy = src[(size_t)anchors + a];
+            const float w = src[(size_t)2 * anchors + a];
+            const float h = src[(size_t)3 * anchors + a];
+            // detector.cu:230-235: strict '>' keeps the first maximal class
+            float best = src[(size_t)4 * anchors + a];
+            int best_j = 0;
+            for (int j = 1; j < classes; ++j) {
+                const float s = src[(size_t)(4 + j) * anchors + a];
+                if (s > best) {
+                    best = s;
+                    best_j = j;
+                }
+            }
+            // detector.cu:237-238: 0.5 is a double literal
+            c.x = (float)fmax((double)cx - 0.5 * (double)w, 0.0);
+            c.y = (float)fmax((double)cy - 0.5 * (double)h, 0.0);
+            c.w = w;
+            c.h = h;
+            c.label = (float)best_j;
+            c.conf = best;
+            pass = !(best < conf_thresh);  // detector.cu:341
+        }
+        int total;
+        const int r = block_rank(pass, wave_tot, total);
+        if (pass) cand[k + r] = c;
+        k += total;
+    }
+    __syncthreads();  // cand[] (global) written by this block is read below
+    __threadfence_block();
+
+    // ---- pass 2 + 3: any-higher NMS, ordered compaction, restore ----
+    const rmr_preparam pp = pps[img];
+    int n_out = 0;
+    for (int base = 0; base < k; base += PP_THREADS) {
+        const int i = base + tid;
+        Cand me{};
+        bool alive = false;
+        if (i < k) {
+            me = cand[i];
+            alive = true;
+        }
+        for (int tile = 0; tile < k; tile += PP_THREADS) {
+            const int j = tile + tid;
+            if (j < k) {
+                const Cand o = cand[j];
+                t_x[tid] = o.x;
+                t_y[tid] = o.y;
+                t_w[tid] = o.w;
+                t_h[tid] = o.h;
+                t_l[tid] = o.label;
+                t_c[tid] = o.conf;
+            }
+            __syncthreads();
+            if (alive) {
+                const int m = min(PP_THREADS, k - tile);
+                for (int q = 0; q < m; ++q) {
+                    // detector.cu:348-356
+                    if (t_l[q] == me.label && t_c[q] > me.conf) {
+                        if (iou_xywh(me.x, me.y, me.w, me.h, t_x[q], t_y[q], t_w[q], t_h[q]) >
+                            nms_thresh) {
+                            alive = false;
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        int total;
+        const int r = block_rank(alive, wave_tot, total);
+        if (alive && n_out + r < cap) {
+            // detector.cpp:258-268
+            rmr_detection d;
+            d.x = clampf((me.x - pp.dw) * pp.ratio, 0.0f, pp.width);
+            d.y = clampf((me.y - pp.dh) * pp.ratio, 0.0f, pp.height);
+            d.width = clampf(me.w * pp.ratio, 0.0f, pp.width - d.x);
+            d.height = clampf(me.h * pp.ratio, 0.0f, pp.height - d.y);
+            d.label = me.label;
+            d.confidence = me.conf;
+            out[(size_t)img * cap + n_out + r] = d;
+        }
+        n_out += total;
+    }
+    if (tid == 0) counts[img] = n_out;
+}
+
+void launch_postprocess(DeviceCtx& ctx, hipStream_t stream, const float* net_out, int n,
+                        int channels, int anchors, int classes, float nms_thresh,
+                        float conf_thresh, const rmr_preparam* pps_dev, void* scratch,
+                        rmr_detection* out_dev, int* counts_dev, int cap) {
+    if (n <= 0) return;
+    ProfScope ps(ctx.prof, stream, "postprocess", 0, (double)n * channels * anchors * 4);
+    postprocess_kernel<<<n, PP_THREADS, 0, stream>>>(net_out, channels, anchors, classes,
+                                                     nms_thresh, conf_thresh, pps_dev,
+                                                     (Cand*)scratch, out_dev, counts_dev, cap);
+    RMR_HIP(hipGetLastError());
+}
+
+size_t postprocess_scratch_bytes(int n, int anchors) { return (size_t)n * anchors * sizeof(Cand); }
+
+// ---- transposeKernel stand-in (detector.cu:185-203), only for its known-answer test ----
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                 int cols) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    for (int r = ty; r < 64; r += 4) {
+        const int sr = blockIdx.y * 64 + r, sc = blockIdx.x * 64 + tx;
+        tile[r][tx] = (sr < rows && sc < cols) ? src[(size_t)sr * cols + sc] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int dr = blockIdx.x * 64 + r, dc = blockIdx.y * 64 + tx;  // dst is [cols][rows]
+        if (dr < cols && dc < rows) dst[(size_t)dr * rows + dc] = tile[tx][r];
+    }
+}
+
+void launch_transpose(hipStream_t stream, const float* src, float* dst, int rows, int cols) {
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    transpose_kernel<<<grid, 256, 0, stream>>>(src, dst, rows, cols);
+    RMR_HIP(hipGetLastError());
+}
+
+}  // namespace rmr

@@ -1,0 +1,205 @@
+"""GPU parity: Locator (update / cluster / search / zoom / transforms) vs the CPU oracle through
+the C-ABI.  Images, foreground lists and cluster partitions are bit-exact; located XYZ within
+1e-3 m (BASELINE.json north_star) -- in practice ~1e-5 m (only the centroid sum associates
+differently)."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+XYZ_TOL_M = 1e-3
+
+
+@pytest.fixture(scope="module")
+def rmr():
+    import rm_radar_amd as r
+    assert r.device_count() >= 1
+    return r
+
+
+def _pair(rmr, oracle, size, K, L2C, W2C, **kw):
+    a = rmr.Locator(size[0], size[1], K, L2C, W2C, **kw)
+    b = oracle.Locator(size[0], size[1], K, L2C, W2C, **kw)
+    return a, b
+
+
+def _same_partition(cid_a, cid_b):
+    return np.array_equal(cid_a, cid_b)
+
+
+def _check_frame(rmr, gpu, cpu, cloud, rects):
+    gpu.update(cloud)
+    cpu.update(cloud)
+    assert np.array_equal(gpu.read_image(gpu.BACKGROUND), cpu.background_image)
+    assert np.array_equal(gpu.read_image(gpu.DEPTH), cpu.depth_image)
+    assert np.array_equal(gpu.read_image(gpu.DIFF), cpu.diff_image)
+    gpu.cluster()
+    cpu.cluster()
+    gx, gp, gc = gpu.foreground()
+    cx, cp, cc = cpu.foreground()
+    assert np.array_equal(gp, cp)
+    assert gx.tobytes() == cx.tobytes()
+    assert gpu.num_clusters == cpu.num_clusters
+    assert _same_partition(gc, cc)
+    robots = [rmr.Robot(rect=tuple(float(v) for v in r)) for r in rects]
+    gpu.search(robots)
+    n_loc = 0
+    for rb, r in zip(robots, rects):
+        want = cpu.search(r)
+        assert (want is None) == (rb.location is None)
+        if want is not None:
+            n_loc += 1
+            assert np.max(np.abs(np.array(rb.location) - want)) <= XYZ_TOL_M
+    return len(gp), cpu.num_clusters, n_loc
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_scene_640(rmr, oracle, seed):
+    clouds, rects = scenes.scene(seed, 30000, (640, 640), scenes.K640, scenes.SAMPLE_L2C)
+    gpu, cpu = _pair(rmr, oracle, (640, 640), scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+    tot_fg = tot_loc = 0
+    for f, cloud in enumerate(clouds):
+        nfg, ncl, nloc = _check_frame(rmr, gpu, cpu, cloud, rects[f])
+        tot_fg += nfg
+        tot_loc += nloc
+    assert tot_fg > 100 and tot_loc >= 4  # the scene really exercises cluster + search
+
+
+def test_scene_sample_calibration_100k(rmr, oracle):
+    # config-4-like: 1920x1080 stream, 100k points, the sample's world transform
+    K = scenes.SAMPLE_K.copy()
+    K[0] *= 1920 / 2592
+    K[1] *= 1080 / 2048
+    clouds, rects = scenes.scene(7, 100000, (1920, 1080), K, scenes.SAMPLE_L2C, n_frames=5)
+    gpu, cpu = _pair(rmr, oracle, (1920, 1080), K, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C)
+    for f, cloud in enumerate(clouds):
+        _check_frame(rmr, gpu, cpu, cloud, rects[f])
+
+
+def test_assets_clouds_plumbing(rmr, oracle):
+    # BASELINE config 1: the reference's own sample clouds (fixture tests/golden/assets_clouds.npz)
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "assets_clouds.npz")
+    data = np.load(path)
+    gpu, cpu = _pair(rmr, oracle, scenes.SAMPLE_SIZE, scenes.SAMPLE_K, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C)
+    for i in range(10):
+        c = np.zeros((10000, 4), np.float32)
+        c[:, :3] = data[f"cloud{i}"]
+        _check_frame(rmr, gpu, cpu, c, [(1000, 800, 400, 300), (200, 1200, 300, 300)])
+
+
+def test_empty_and_null_cloud(rmr, oracle):
+    clouds, _ = scenes.scene(3, 5000, (640, 640), scenes.K640, scenes.SAMPLE_L2C, n_frames=3)
+    gpu, cpu = _pair(rmr, oracle, (640, 640), scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+    for c in (clouds[0], None, clouds[1], np.zeros((0, 4), np.float32), clouds[2]):
+        gpu.update(c)
+        cpu.update(c)
+        assert np.array_equal(gpu.read_image(gpu.DIFF), cpu.diff_image)
+        assert np.array_equal(gpu.read_image(gpu.BACKGROUND), cpu.background_image)
+        gpu.cluster()
+        cpu.cluster()
+        assert np.array_equal(gpu.foreground()[1], cpu.foreground()[1])
+
+
+def test_duplicate_pixels_last_index_wins(rmr, oracle):
+    # many points per pixel, out-of-range / behind-camera / NaN-producing points, strides 12 and 16
+    rng = np.random.default_rng(4)
+    eye3, eye4 = np.eye(3, dtype=np.float32), np.eye(4, dtype=np.float32)
+    kw = dict(zoom_factor=1.0, queue_size=2, min_depth_diff=0.5, max_depth_diff=50.0, max_distance=1e9)
+    gpu, cpu = _pair(rmr, oracle, (32, 24), eye3, eye4, eye4, **kw)
+    for stride in (3, 4):
+        n = 4000
+        d = rng.uniform(1, 100, n).astype(np.float32)
+        u = rng.uniform(-2, 34, n).astype(np.float32)
+        v = rng.uniform(-2, 26, n).astype(np.float32)
+        c = np.zeros((n, stride), np.float32)
+        c[:, 0], c[:, 1], c[:, 2] = u * d, v * d, d
+        c[::50, 2] = -c[::50, 2]         # behind the camera
+        c[::97, :3] = 0                  # exact zeros are dropped
+        c[5, :3] = (1.0, 1.0, 0.0)       # d == 0 -> inf / NaN pixel coordinates
+        gpu.update(c)
+        cpu.update(c)
+        assert np.array_equal(gpu.read_image(gpu.DEPTH), cpu.depth_image)
+        assert np.array_equal(gpu.read_image(gpu.BACKGROUND), cpu.background_image)
+        assert np.array_equal(gpu.read_image(gpu.DIFF), cpu.diff_image)
+
+
+# ---- the reference's own locator tests (test/locate/locator_test.cpp) on the GPU -----------
+
+def _test_pair(rmr, oracle, kat):
+    k = kat["locator_test"]
+    eye3, eye4 = np.eye(3, dtype=np.float32), np.eye(4, dtype=np.float32)
+    kw = dict(zoom_factor=k["zoom_factor"], queue_size=k["queue_size"],
+              min_depth_diff=k["min_depth_diff"], max_depth_diff=k["max_depth_diff"],
+              cluster_tolerance=k["cluster_tolerance"], min_cluster_size=k["min_cluster_size"],
+              max_cluster_size=k["max_cluster_size"], max_distance=k["max_distance"])
+    return _pair(rmr, oracle, (k["image_width"], k["image_height"]), eye3, eye4, eye4, **kw)
+
+
+def test_ref_zoom(rmr, oracle, kat):
+    gpu, cpu = _test_pair(rmr, oracle, kat)
+    r = kat["locator_test"]["zoom_rect"]
+    assert gpu.zoom(r) == cpu.zoom(r)
+    assert gpu.zoom(r)[2:] == (int(r[2] * 0.5), int(r[3] * 0.5))
+    for rect in [(0, 0, 640, 480), (-50, -50, 100, 100), (600, 440, 100, 100), (700, 500, 10, 10),
+                 (101, 77, 33, 55), (5, 5, 1, 1)]:
+        assert gpu.zoom(rect) == cpu.zoom(rect)
+
+
+def test_ref_coordinate_transform(rmr, oracle, kat):
+    gpu, cpu = _test_pair(rmr, oracle, kat)
+    p = np.array(kat["locator_test"]["transform_point"], np.float32)
+    assert np.array_equal(gpu.lidar_to_world(p), p)
+    cam = gpu.lidar_to_camera(p)
+    assert cam.tobytes() == cpu.lidar_to_camera(p).tobytes()
+    np.testing.assert_allclose(gpu.camera_to_lidar(cam), p, rtol=4e-7)
+    g2, c2 = _pair(rmr, oracle, scenes.SAMPLE_SIZE, scenes.SAMPLE_K, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C)
+    for q in ([19427, 2560, 1833], [6100, -3000, 250], [28000, 9000, -1500]):
+        q = np.array(q, np.float32)
+        for name in ("lidar_to_world", "lidar_to_camera", "camera_to_lidar"):
+            assert getattr(g2, name)(q).tobytes() == getattr(c2, name)(q).tobytes()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_ref_two_blob_cluster_and_search(rmr, oracle, kat, seed):
+    from test_oracle_kat import _two_blobs
+    k = kat["locator_test"]
+    gpu, cpu = _test_pair(rmr, oracle, kat)
+    img = _two_blobs(k, seed)
+    gpu.write_image(gpu.DIFF, img)
+    cpu.diff_image[:] = img
+    gpu.cluster()
+    cpu.cluster()
+    assert gpu.num_clusters == k["expect_clusters"] == cpu.num_clusters
+    gx, gp, gc = gpu.foreground()
+    cx, cp, cc = cpu.foreground()
+    assert np.array_equal(gp, cp) and np.array_equal(gc, cc) and gx.tobytes() == cx.tobytes()
+    rb = rmr.Robot(rect=tuple(float(v) for v in k["search_rect"]))
+    gpu.search([rb])
+    want = cpu.search(k["search_rect"])
+    assert rb.location is not None and want is not None
+    assert np.max(np.abs(np.array(rb.location) - want)) <= XYZ_TOL_M
+
+
+def test_keep_and_search_kept(rmr, oracle):
+    clouds, rects = scenes.scene(5, 20000, (640, 640), scenes.K640, scenes.SAMPLE_L2C, n_frames=6)
+    eye4 = np.eye(4, dtype=np.float32)
+    gpu = rmr.Locator(640, 640, scenes.K640, scenes.SAMPLE_L2C, eye4, max_frames=6)
+    cpu = oracle.Locator(640, 640, scenes.K640, scenes.SAMPLE_L2C, eye4)
+    wants = []
+    for f, c in enumerate(clouds):
+        gpu.update(c)
+        gpu.cluster()
+        gpu.keep(f)
+        cpu.update(c)
+        cpu.cluster()
+        wants.append([cpu.search(r) for r in rects[f]])
+    for f in range(len(clouds)):
+        robots = [rmr.Robot(rect=tuple(float(v) for v in r)) for r in rects[f]]
+        gpu.search(robots, frame=f)
+        for rb, want in zip(robots, wants[f]):
+            assert (want is None) == (rb.location is None)
+            if want is not None:
+                assert np.max(np.abs(np.array(rb.location) - want)) <= XYZ_TOL_M

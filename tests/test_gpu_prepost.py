@@ -1,0 +1,195 @@
+"""GPU parity: fused letterbox and fused decode+NMS+restore kernels vs the CPU oracle, through
+the C-ABI.  Integer/byte/index work => bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rmr():
+    import rm_radar_amd as r
+    assert r.device_count() >= 1, "no gfx950 device: the HIP path has no fallback"
+    return r
+
+
+def ramp():
+    return np.arange(48, dtype=np.uint8).reshape(4, 4, 3)
+
+
+# ---- the reference's own kernel known-answer tests, reproduced on the GPU ----------------
+
+def test_kat_resize_double(kat, rmr):
+    out = rmr.letterbox([ramp()], 8, 8, 0, 0, 8, 8, fill=128, fmt="u8")
+    assert out.reshape(-1).tolist() == kat["resize_double"]["truth"]
+
+
+def test_kat_resize_half(kat, rmr):
+    out = rmr.letterbox([ramp()], 2, 2, 0, 0, 2, 2, fmt="u8")
+    assert out.reshape(-1).tolist() == kat["resize_half"]["truth"]
+
+
+def test_kat_copy_make_border(kat, rmr):
+    k = kat["copy_make_border"]
+    out = rmr.letterbox([ramp()], 4, 4, k["top"], k["left"], 4 + k["left"] + k["right"],
+                        4 + k["top"] + k["bottom"], fill=128, fmt="u8")
+    assert out.reshape(-1).tolist() == k["truth"]
+
+
+def test_kat_blob(kat, rmr):
+    scale = np.float32(kat["blob"]["scale"])
+    out = rmr.letterbox([ramp()], 4, 4, 0, 0, 4, 4, scale=float(scale), fmt="f32")[0]
+    want = (ramp()[:, :, ::-1].astype(np.float32) * scale).transpose(2, 0, 1)
+    assert np.array_equal(out, want)
+
+
+def test_kat_transpose(kat, rmr):
+    t = kat["transpose"]
+    src = np.arange(t["rows"] * t["cols"], dtype=np.float32).reshape(t["rows"], t["cols"])
+    assert np.array_equal(rmr.transpose(src), src.T)
+
+
+@pytest.mark.parametrize("name", ["bus", "zidane"])
+def test_kat_preparam(kat, rmr, name):
+    g = kat["preparam"][name]
+    p = rmr.preparam(g["width"], g["height"], 640, 640)
+    assert (p.width, p.height, p.dw, p.dh) == (g["width"], g["height"], g["dw"], g["dh"])
+
+
+# ---- preprocess vs oracle ------------------------------------------------------------------
+
+@pytest.mark.parametrize("w,h", [(640, 640), (810, 1080), (1280, 720), (2592, 2048), (1920, 1080),
+                                 (37, 211), (333, 17), (1, 1), (641, 639)])
+def test_preprocess_matches_oracle(rmr, oracle, w, h):
+    rng = np.random.default_rng(w * 10007 + h)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    blob, pps = rmr.preprocess([img])
+    want, wp = oracle.preprocess(img)
+    assert pps[0].astuple() == wp.astuple()
+    assert rmr.letterbox_geometry(pps[0]) == tuple(
+        np.array(oracle.letterbox_geometry(wp))[[0, 1, 2, 4]].tolist())
+    assert np.array_equal(blob[0], want)
+
+
+def test_preprocess_crops_batch_matches_oracle(rmr, oracle):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    crops = [(0, 0, 1920, 1080), (100, 200, 333, 177), (1500, 900, 420, 180), (7, 3, 50, 400),
+             (960, 540, 1, 1), (1000, 100, 655, 655)]
+    blob, pps = rmr.preprocess([img] * len(crops), crops=crops)
+    for i, c in enumerate(crops):
+        want, wp = oracle.preprocess(img, crop=c)
+        assert pps[i].astuple() == wp.astuple()
+        assert np.array_equal(blob[i], want), f"crop {c}"
+
+
+def test_preprocess_strided_and_device_image(rmr, oracle):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(11)
+    big = rng.integers(0, 256, (300, 500, 3), dtype=np.uint8)
+    view = big[:, :400]  # row stride 1500 > 400*3
+    blob, _ = rmr.preprocess([view])
+    want, _ = oracle.preprocess(np.ascontiguousarray(view))
+    assert np.array_equal(blob[0], want)
+    dev = torch.from_numpy(np.ascontiguousarray(view)).cuda()
+    blob2, _ = rmr.preprocess([dev])
+    assert np.array_equal(blob2[0], want)
+
+
+def test_preprocess_bad_arguments(rmr):
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.preprocess([np.zeros((4, 4, 3), np.uint8)], crops=[(2, 2, 5, 5)])
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.preprocess([np.zeros((4, 4), np.uint8)])
+
+
+# ---- postprocess vs oracle -------------------------------------------------------------------
+
+def _random_head(rng, classes, anchors=8400, frac=0.03):
+    out = np.zeros((4 + classes, anchors), np.float32)
+    out[0] = rng.uniform(0, 640, anchors)
+    out[1] = rng.uniform(0, 640, anchors)
+    out[2] = rng.uniform(2, 200, anchors)
+    out[3] = rng.uniform(2, 200, anchors)
+    scores = rng.uniform(0, 0.2, (classes, anchors)).astype(np.float32)
+    hot = rng.random(anchors) < frac
+    scores[rng.integers(0, classes, anchors), np.arange(anchors)] += np.where(
+        hot, rng.uniform(0.1, 0.8, anchors), 0).astype(np.float32)
+    out[4:] = scores
+    return out
+
+
+@pytest.mark.parametrize("classes,frac", [(1, 0.03), (12, 0.03), (12, 0.4), (80, 0.1), (1, 1.0)])
+def test_postprocess_matches_oracle(rmr, oracle, classes, frac):
+    rng = np.random.default_rng(classes * 31 + int(frac * 100))
+    n = 3
+    heads = np.stack([_random_head(rng, classes, frac=frac) for _ in range(n)])
+    sizes = [(2592, 2048), (640, 640), (333, 517)]
+    pps = [rmr.preparam(w, h) for w, h in sizes]
+    got = rmr.postprocess(heads, classes, 0.65, 0.25, pps)
+    for i in range(n):
+        want = oracle.postprocess(heads[i], classes, 0.65, 0.25, oracle.preparam(*sizes[i]))
+        assert len(got[i]) == len(want)
+        assert got[i].tobytes() == want.tobytes()
+
+
+def test_postprocess_clustered_boxes_suppress(rmr, oracle):
+    # heavy overlap: many candidates around a few centres so NMS really suppresses
+    rng = np.random.default_rng(99)
+    classes, anchors = 12, 8400
+    out = np.zeros((4 + classes, anchors), np.float32)
+    centres = rng.uniform(100, 540, (6, 2))
+    which = rng.integers(0, 6, anchors)
+    out[0] = centres[which, 0] + rng.normal(0, 6, anchors)
+    out[1] = centres[which, 1] + rng.normal(0, 6, anchors)
+    out[2] = 80 + rng.normal(0, 5, anchors)
+    out[3] = 60 + rng.normal(0, 5, anchors)
+    out[4 + which % classes, np.arange(anchors)] = rng.uniform(0.2, 0.99, anchors)
+    pp = [rmr.preparam(1920, 1080)]
+    got = rmr.postprocess(out[None], classes, 0.65, 0.5, pp)[0]
+    want = oracle.postprocess(out, classes, 0.65, 0.5, oracle.preparam(1920, 1080))
+    assert 0 < len(want) < 400
+    assert got.tobytes() == want.tobytes()
+
+
+def test_postprocess_edge_cases(rmr, oracle):
+    # first-max tie (Q7), clipped x/y with unchanged w/h, equal-confidence duplicates,
+    # chain A>B>C (any-higher vs greedy), touching boxes, zero-area (NaN IoU), conf == thresh
+    classes, anchors = 3, 64
+    out = np.zeros((4 + classes, anchors), np.float32)
+
+    def put(a, cx, cy, w, h, scores):
+        out[0:4, a] = (cx, cy, w, h)
+        out[4:, a] = scores
+
+    put(0, 10, 10, 40, 40, (0.9, 0.9, 0.1))        # tie -> label 0; x,y clip to 0
+    put(1, 100, 100, 50, 50, (0.8, 0, 0))
+    put(2, 100, 100, 50, 50, (0.8, 0, 0))          # equal-conf duplicate: both survive
+    put(3, 300, 300, 100, 100, (0, 0.9, 0))        # A
+    put(4, 310, 300, 100, 100, (0, 0.8, 0))        # B suppressed by A
+    put(5, 330, 300, 100, 100, (0, 0.7, 0))        # C: IoU(A,C) low, IoU(B,C) high -> any-higher drops C
+    put(6, 500, 500, 20, 20, (0, 0, 0.6))
+    put(7, 520, 500, 20, 20, (0, 0, 0.7))          # touching boxes: IoU 0
+    put(8, 50, 400, 0, 0, (0.5, 0, 0))
+    put(9, 50, 400, 0, 0, (0.6, 0, 0))             # zero area: NaN IoU -> not suppressed
+    put(10, 600, 50, 30, 30, (0.25, 0, 0))         # conf == thresh is kept ('<' test)
+    put(11, 600, 120, 30, 30, (0.24999, 0, 0))     # just below: dropped
+    pp = rmr.preparam(640, 640)
+    got = rmr.postprocess(out[None], classes, 0.65, 0.25, [pp])[0]
+    want = oracle.postprocess(out, classes, 0.65, 0.25, oracle.preparam(640, 640))
+    assert got.tobytes() == want.tobytes()
+    labels = {int(i) for i in np.nonzero(np.isin(got["x"], [0.0]))[0]}
+    assert len(got) == len(want) and len(got) >= 8 and labels is not None
+
+
+def test_postprocess_empty_and_capacity(rmr):
+    heads = np.zeros((2, 5, 8400), np.float32)
+    got = rmr.postprocess(heads, 1, 0.65, 0.25, [rmr.preparam(640, 640)] * 2)
+    assert [len(g) for g in got] == [0, 0]
+    heads[:, 4, :] = 0.9
+    heads[:, 0, :] = np.arange(8400) * 50.0  # disjoint boxes: every anchor survives
+    heads[:, 2:4, :] = 10
+    with pytest.raises(rmr.CapacityError):
+        rmr.postprocess(heads, 1, 0.65, 0.25, [rmr.preparam(640, 640)] * 2, cap=100)
+    got = rmr.postprocess(heads, 1, 0.65, 0.25, [rmr.preparam(640, 640)] * 2)
+    assert [len(g) for g in got] == [8400, 8400]
