@@ -1,0 +1,180 @@
+// api_detect.cpp -- C-ABI entry points (include/rmr.h) for Detector, RobotDetector and the
+// single-layer conv hook.
+#include "common.h"
+#include "conv_igemm.h"
+#include "detector.h"
+
+using namespace rmr;
+
+struct rmr_detector {
+    Detector impl;
+    explicit rmr_detector(const rmr_detector_cfg& c) : impl(c) {}
+};
+struct rmr_robot_detector {
+    RobotDetector impl;
+    explicit rmr_robot_detector(const rmr_robot_detector_cfg& c) : impl(c) {}
+};
+
+extern "C" {
+
+// detector.h:87-93 defaults
+void rmr_detector_cfg_default(rmr_detector_cfg* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->nms_thresh = 0.65f;
+    c->conf_thresh = 0.25f;
+    c->input_width = 640;
+    c->input_height = 640;
+    c->input_channels = 3;
+    c->max_batch_size = 1;
+}
+
+rmr_status rmr_detector_create(const rmr_detector_cfg* cfg, rmr_detector** out) {
+    return guarded([&] {
+        if (!cfg || !out) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_detector_create: null argument");
+        *out = new rmr_detector(*cfg);
+    });
+}
+
+void rmr_detector_destroy(rmr_detector* det) { delete det; }
+
+rmr_status rmr_detector_detect(rmr_detector* det, const rmr_image* imgs, const int* crops, int n,
+                               rmr_detection* out, int* counts, int cap) {
+    return guarded([&] {
+        if (!det) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_detector_detect: null detector");
+        det->impl.detect(imgs, crops, n, out, counts, cap);
+    });
+}
+
+rmr_status rmr_detector_infer(rmr_detector* det, const rmr_image* imgs, const int* crops, int n, float* net_out,
+                              rmr_preparam* pp) {
+    return guarded([&] {
+        if (!det) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_detector_infer: null detector");
+        det->impl.infer(imgs, crops, n, net_out, pp);
+    });
+}
+
+int rmr_detector_anchors(const rmr_detector* det) { return det ? const_cast<rmr_detector*>(det)->impl.net().anchors() : 0; }
+int rmr_detector_channels(const rmr_detector* det) { return det ? const_cast<rmr_detector*>(det)->impl.net().channels() : 0; }
+double rmr_detector_flops_per_image(const rmr_detector* det) {
+    return det ? const_cast<rmr_detector*>(det)->impl.net().flops_per_image() : 0.0;
+}
+
+// detector.h:173-180 defaults
+void rmr_robot_detector_cfg_default(rmr_robot_detector_cfg* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->iou_thresh = 0.75f;
+    c->car_nms_thresh = 0.65f;
+    c->car_conf_thresh = 0.25f;
+    c->armor_nms_thresh = 0.65f;
+    c->armor_conf_thresh = 0.50f;
+    c->input_width = 640;
+    c->input_height = 640;
+    c->input_channels = 3;
+    c->max_frames = 1;
+}
+
+rmr_status rmr_robot_detector_create(const rmr_robot_detector_cfg* cfg, rmr_robot_detector** out) {
+    return guarded([&] {
+        if (!cfg || !out) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_robot_detector_create: null argument");
+        if (!cfg->car_engine_path || !cfg->armor_engine_path)
+            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_robot_detector_create: null engine path");
+        *out = new rmr_robot_detector(*cfg);
+    });
+}
+
+void rmr_robot_detector_destroy(rmr_robot_detector* rd) { delete rd; }
+
+rmr_status rmr_robot_detector_detect(rmr_robot_detector* rd, const rmr_image* img, rmr_robot* out, int* n_out,
+                                     int cap) {
+    return guarded([&] {
+        if (!rd) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_robot_detector_detect: null detector");
+        rd->impl.detect_batch(img, 1, nullptr, 0, out, n_out, cap);
+    });
+}
+
+rmr_status rmr_robot_detector_detect_batch(rmr_robot_detector* rd, const rmr_image* imgs, int n_frames,
+                                           const int* forced_crops, int forced_per_frame, rmr_robot* out,
+                                           int* n_out, int cap) {
+    return guarded([&] {
+        if (!rd) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_robot_detector_detect_batch: null detector");
+        rd->impl.detect_batch(imgs, n_frames, forced_crops, forced_per_frame, out, n_out, cap);
+    });
+}
+
+// One layer through the conv engine with host f32 tensors (parity tests of the kernel).
+rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, const float* wt, const float* bias,
+                      int cout, int kh, int kw, int stride, int pad, int silu, const float* residual, float* y,
+                      int tile) {
+    return guarded([&] {
+        if (!x || !wt || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0)
+            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: bad arguments");
+        DeviceCtx& ctx = device_ctx(device);
+        const int cin_pad = (cin + 7) / 8 * 8, cout_pad = (cout + 15) / 16 * 16;
+        const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+        if (ho <= 0 || wo <= 0) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: empty output");
+        const size_t npx_in = (size_t)n * h * w, npx_out = (size_t)n * ho * wo;
+        std::vector<__half> hx(npx_in * cin_pad, __float2half(0.f)), hr;
+        for (size_t p = 0; p < npx_in; ++p)
+            for (int c = 0; c < cin; ++c) hx[p * cin_pad + c] = __float2half(x[p * cin + c]);
+        if (residual) {
+            hr.assign(npx_out * cout_pad, __float2half(0.f));
+            for (size_t p = 0; p < npx_out; ++p)
+                for (int c = 0; c < cout; ++c) hr[p * cout_pad + c] = __float2half(residual[p * cout + c]);
+        }
+        std::vector<__half> packed;
+        ConvArgs a{};
+        pack_conv_weights(wt, cout, cin, kh, kw, cin_pad, cout_pad, packed, a.K, a.Kp);
+        std::vector<float> b(cout_pad, 0.f);
+        if (bias) std::copy(bias, bias + cout, b.begin());
+        DevBuf<__half> dx, dw, dr;
+        DevBuf<float> db, dy;
+        dx.alloc(hx.size());
+        dw.alloc(packed.size());
+        db.alloc(b.size());
+        dy.alloc(npx_out * cout_pad);
+        RMR_HIP(hipMemcpyAsync(dx.p, hx.data(), hx.size() * sizeof(__half), hipMemcpyHostToDevice, ctx.stream));
+        RMR_HIP(hipMemcpyAsync(dw.p, packed.data(), packed.size() * sizeof(__half), hipMemcpyHostToDevice, ctx.stream));
+        RMR_HIP(hipMemcpyAsync(db.p, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice, ctx.stream));
+        if (residual) {
+            dr.alloc(hr.size());
+            RMR_HIP(hipMemcpyAsync(dr.p, hr.data(), hr.size() * sizeof(__half), hipMemcpyHostToDevice, ctx.stream));
+        }
+        a.in = dx.p;
+        a.in_cs = cin_pad;
+        a.N = n;
+        a.H = h;
+        a.W = w;
+        a.Cin = cin_pad;
+        a.Ho = ho;
+        a.Wo = wo;
+        a.KH = kh;
+        a.KW = kw;
+        a.stride = stride;
+        a.pad = pad;
+        a.wt = dw.p;
+        a.bias = db.p;
+        a.out32 = dy.p;
+        a.out_cs = cout_pad;
+        if (residual) {
+            a.res = dr.p;
+            a.res_cs = cout_pad;
+        }
+        a.Cout_pad = cout_pad;
+        a.M = (int)npx_out;
+        a.act = silu;
+        int t = tile;
+        if (t < 0) t = conv_pick_tile(a.M, cout_pad, ctx.num_cus);
+        if (t >= conv_num_tiles() || cout_pad % conv_tile(t).bn)
+            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: tile %d cannot produce %d channels", t, cout_pad);
+        launch_conv(ctx, ctx.stream, a, t);
+        std::vector<float> hy(npx_out * cout_pad);
+        RMR_HIP(hipMemcpyAsync(hy.data(), dy.p, hy.size() * sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
+        RMR_HIP(hipStreamSynchronize(ctx.stream));
+        for (size_t p = 0; p < npx_out; ++p)
+            for (int c = 0; c < cout; ++c) y[p * cout + c] = hy[p * cout_pad + c];
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// conv_igemm.h -- implicit-GEMM convolution on MFMA (f16 in, f32 accumulate), NHWC.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace rmr {
+
+// One conv + bias (+SiLU) (+residual) over strided NHWC views.  Every tensor is addressed as
+// base + pixel * cstride + coff, so a layer can read or write a channel slice of a wider
+// buffer (C2f / SPPF / FPN concats are never materialised by a copy).
+struct ConvArgs {
+    const __half* in;
+    int in_cs, in_co;  // elements per pixel of the input buffer, first channel consumed
+    int N, H, W, Cin;  // Cin: channels consumed, multiple of 8
+    int Ho, Wo, KH, KW, stride, pad;
+    const __half* wt;   // packed [Cout_pad][Kp], k = (kh*KW + kw)*Cin + ci, zero padded
+    const float* bias;  // [Cout_pad]
+    __half* out;        // f16 output view (or null when out32 is set)
+    float* out32;       // f32 output view
+    int out_cs, out_co;
+    const __half* res;  // optional residual view, added after the activation
+    int res_cs, res_co;
+    int Cout_pad;       // multiple of the tile's BN
+    int K, Kp, M;       // K = KH*KW*Cin, Kp = K rounded up to 32, M = N*Ho*Wo
+    int act;            // 1 = SiLU
+    double flops;       // algorithmic FLOPs of this launch (true channel counts), for profiling
+};
+
+struct ConvTile {
+    int bm, bn;
+};
+
+int conv_num_tiles();
+ConvTile conv_tile(int id);
+// best tile for (M, Cout_pad) on a chip with num_cus compute units
+int conv_pick_tile(int M, int cout_pad, int num_cus);
+void launch_conv(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a, int tile);
+
+// Packs OIHW f32 weights into the engine's [Cout_pad][Kp] f16 layout (host side).
+// cin_pad >= cin: extra input channels get zero weights.
+void pack_conv_weights(const float* w_oihw, int cout, int cin, int kh, int kw, int cin_pad,
+                       int cout_pad, std::vector<__half>& out, int& K, int& Kp);
+
+}  // namespace rmr

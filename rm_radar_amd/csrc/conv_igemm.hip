@@ -1,0 +1,297 @@
+// conv_igemm.hip -- implicit-GEMM convolution for gfx950: v_mfma_f32_16x16x32_f16, 64-lane
+// waves, LDS-staged operand tiles, fused bias + SiLU + residual epilogue.
+//
+// GEMM view: out[M = N*Ho*Wo][Cout] = im2col(in)[M][K = KH*KW*Cin] * W^T.
+// Activations are NHWC f16, so for a fixed (kh,kw) the Cin values of a pixel are contiguous:
+// the im2col row is gathered on the fly in 16-byte chunks (8 channels) straight from the
+// strided input view, never materialised.  Weights are pre-packed [Cout][K] (K contiguous), i.e.
+// both operands are "K-inner" and both fragments are single ds_read_b128 per lane.
+//
+// The MFMA operands are swapped -- D = W_frag(16 cout x 32 k) * X_frag(32 k x 16 pixels) -- so
+// that each lane ends with 4 CONSECUTIVE output channels of one pixel (D row = (lane>>4)*4+r,
+// D col = lane&15): the NHWC epilogue is one 8-byte store per 16x16 tile per lane, 32 B
+// contiguous per pixel per tile, instead of 2-byte scattered stores.
+//
+// Work decomposition: 256 threads = 4 waves arranged WM x WN; each wave owns MREP x NREP
+// 16x16 accumulator tiles; workgroup tile BM x BN = (WM*MREP*16) x (WN*NREP*16), BK = 32.
+// Pipeline: register-staged double buffering -- global loads for K-step t+1 are issued before
+// the MFMAs of step t and written to the other LDS buffer after them; one barrier per K-step.
+// LDS rows are padded to 80 B (40 halves) so the 16 rows a lane group reads spread over banks.
+// Workgroup ids are remapped so that the N-tiles sharing one activation row-block run on the
+// same XCD (its 4 MiB L2 then serves the re-reads of that block).
+#include "conv_igemm.h"
+
+namespace rmr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 8;  // padded LDS row, in halves (80 B)
+
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
+template <int WM, int WN, int MREP, int NREP>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int BM = WM * MREP * 16;
+    constexpr int BN = WN * NREP * 16;
+    constexpr int RPI = 64;  // rows staged per pass: 256 threads / 4 chunks per row
+    constexpr int A_IT = BM / RPI;
+    constexpr int B_IT = (BN + RPI - 1) / RPI;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BM % RPI == 0, "BM must be a multiple of 64");
+
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BN * LDK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: logical id runs through the N-tiles of one M-block first, and
+    // consecutive logical ids are dispatched to the same XCD (block b -> XCD b % 8).
+    const int nt_count = a.Cout_pad / BN;
+    const int nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int xcd = blockIdx.x & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int m0 = (lid / nt_count) * BM;
+    const int n0 = (lid % nt_count) * BN;
+
+    // ---- per-thread im2col bookkeeping (rows are fixed across the K loop) ----
+    const int kc = tid & 3;     // 16-byte chunk within the 32-wide K slice
+    const int row0 = tid >> 2;  // 0..63
+    long a_base[A_IT];
+    int a_hw[A_IT];     // (ih0 << 16) | (iw0 & 0xffff)
+    unsigned a_ok = 0;  // bit i: row i is a real output pixel
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + row0 + i * RPI;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int ow = mm % a.Wo;
+        const int t = mm / a.Wo;
+        const int oh = t % a.Ho;
+        const int n = t / a.Ho;
+        const int ih0 = oh * a.stride - a.pad;
+        const int iw0 = ow * a.stride - a.pad;
+        a_base[i] = ((long)(n * a.H + ih0) * a.W + iw0) * a.in_cs + a.in_co;
+        a_hw[i] = ih0 * 65536 + (iw0 & 0xffff);
+        a_ok |= (ok ? 1u : 0u) << i;
+    }
+    // position of this thread's chunk inside the filter window, advanced by BK per step
+    int k_ci, k_kw, k_kh;
+    {
+        const int k = kc * 8;
+        k_ci = k % a.Cin;
+        const int t = k / a.Cin;
+        k_kw = t % a.KW;
+        k_kh = t / a.KW;
+    }
+    const _Float16* wrow[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int r = row0 + i * RPI;
+        wrow[i] = (const _Float16*)a.wt + (long)(n0 + (r < BN ? r : 0)) * a.Kp + kc * 8;
+    }
+
+    uint4 a_reg[A_IT], b_reg[B_IT];
+    auto load_tiles = [&](int kt) {
+        const long delta = (long)(k_kh * a.W + k_kw) * a.in_cs + k_ci;
+        const bool kok = k_kh < a.KH;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int ih = (a_hw[i] >> 16) + k_kh;
+            const int iw = (int)(short)(a_hw[i] & 0xffff) + k_kw;
+            const bool ok = kok && ((a_ok >> i) & 1u) && (unsigned)ih < (unsigned)a.H &&
+                            (unsigned)iw < (unsigned)a.W;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *(const uint4*)((const _Float16*)a.in + a_base[i] + delta);
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) b_reg[i] = *(const uint4*)(wrow[i] + (long)kt * BK);
+        // advance the filter-window position to the next K step
+        k_ci += BK;
+        while (k_ci >= a.Cin) {
+            k_ci -= a.Cin;
+            if (++k_kw == a.KW) {
+                k_kw = 0;
+                ++k_kh;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            *(uint4*)&As[buf][(row0 + i * RPI) * LDK + kc * 8] = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int r = row0 + i * RPI;
+            if (r < BN) *(uint4*)&Bs[buf][r * LDK + kc * 8] = b_reg[i];
+        }
+    };
+
+    floatx4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.Kp / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int frag_row = lane & 15;
+    const int frag_k = (lane >> 4) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+
+        half8 xf[MREP], wf[NREP];
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+            xf[i] = *(const half8*)&As[buf][((wm * MREP + i) * 16 + frag_row) * LDK + frag_k];
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+            wf[j] = *(const half8*)&Bs[buf][((wn * NREP + j) * 16 + frag_row) * LDK + frag_k];
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, SiLU, residual, store 4 consecutive channels per lane ----
+    const int px = lane & 15;
+    const int cq = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + (wm * MREP + i) * 16 + px;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int n = n0 + (wn * NREP + j) * 16 + cq;
+            const float4 b = *(const float4*)(a.bias + n);
+            float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z,
+                          acc[i][j][3] + b.w};
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+            }
+            if (a.res) {
+                union {
+                    uint2 u;
+                    _Float16 h[4];
+                } rr;
+                rr.u = *(const uint2*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr.h[r];
+            }
+            if (a.out32) {
+                *(float4*)(a.out32 + (long)m * a.out_cs + a.out_co + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                union {
+                    uint2 u;
+                    _Float16 h[4];
+                } o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.h[r] = (_Float16)v[r];
+                *(uint2*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + n) = o.u;
+            }
+        }
+    }
+}
+
+// ---- tile table ------------------------------------------------------------------------------
+
+struct TileDef {
+    int bm, bn;
+    void (*kernel)(const ConvArgs);
+};
+
+#define TILE(WM, WN, MR, NR) \
+    { WM * MR * 16, WN * NR * 16, conv_igemm_kernel<WM, WN, MR, NR> }
+
+static const TileDef kTiles[] = {
+    TILE(4, 1, 4, 6),  // 0: 256 x 96
+    TILE(2, 2, 4, 3),  // 1: 128 x 96
+    TILE(2, 2, 2, 3),  // 2:  64 x 96
+    TILE(4, 1, 4, 3),  // 3: 256 x 48
+    TILE(4, 1, 2, 3),  // 4: 128 x 48
+    TILE(4, 1, 1, 3),  // 5:  64 x 48
+    TILE(4, 1, 4, 4),  // 6: 256 x 64
+    TILE(2, 2, 4, 2),  // 7: 128 x 64
+    TILE(2, 2, 2, 2),  // 8:  64 x 64
+    TILE(2, 2, 4, 4),  // 9: 128 x 128
+    TILE(2, 2, 2, 4),  // 10: 64 x 128
+    TILE(4, 1, 4, 2),  // 11: 256 x 32
+    TILE(4, 1, 1, 2),  // 12:  64 x 32
+    TILE(4, 1, 4, 1),  // 13: 256 x 16
+    TILE(4, 1, 1, 1),  // 14:  64 x 16
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+int conv_num_tiles() { return kNumTiles; }
+ConvTile conv_tile(int id) { return ConvTile{kTiles[id].bm, kTiles[id].bn}; }
+
+int conv_pick_tile(int M, int cout_pad, int num_cus) {
+    // widest BN that divides Cout_pad (fewer re-reads of the activation tile) ...
+    int bn = 16;
+    for (int cand : {128, 96, 64, 48, 32, 16})
+        if (cout_pad % cand == 0) {
+            bn = cand;
+            break;
+        }
+    // ... then the tallest BM that still yields >= 2 workgroups per CU; else the shortest
+    int best = -1, best_bm = 0, smallest = -1, smallest_bm = 1 << 30;
+    for (int t = 0; t < kNumTiles; ++t) {
+        if (kTiles[t].bn != bn) continue;
+        const long blocks = (long)((M + kTiles[t].bm - 1) / kTiles[t].bm) * (cout_pad / bn);
+        if (blocks >= 2L * num_cus && kTiles[t].bm > best_bm) {
+            best = t;
+            best_bm = kTiles[t].bm;
+        }
+        if (kTiles[t].bm < smallest_bm) {
+            smallest = t;
+            smallest_bm = kTiles[t].bm;
+        }
+    }
+    return best >= 0 ? best : smallest;
+}
+
+void launch_conv(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a, int tile) {
+    if (tile < 0 || tile >= kNumTiles) fail(RMR_ERR_INVALID_ARGUMENT, "conv: tile %d out of range", tile);
+    const TileDef& t = kTiles[tile];
+    if (a.Cout_pad % t.bn) fail(RMR_ERR_LOGIC, "conv: Cout_pad %d not a multiple of tile BN %d", a.Cout_pad, t.bn);
+    if (a.Cin % 8 || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 || a.Kp % BK)
+        fail(RMR_ERR_LOGIC, "conv: misaligned view (Cin %d in_cs %d in_co %d out_cs %d out_co %d Kp %d)",
+             a.Cin, a.in_cs, a.in_co, a.out_cs, a.out_co, a.Kp);
+    const int grid = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
+    const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad +
+                                (double)a.Cout_pad * a.K);
+    ProfScope ps(ctx.prof, stream, "conv_igemm_f16", flops, bytes);
+    t.kernel<<<grid, 256, 0, stream>>>(a);
+    RMR_HIP(hipGetLastError());
+}
+
+void pack_conv_weights(const float* w, int cout, int cin, int kh, int kw, int cin_pad, int cout_pad,
+                       std::vector<__half>& out, int& K, int& Kp) {
+    K = kh * kw * cin_pad;
+    Kp = (K + BK - 1) / BK * BK;
+    out.assign((size_t)cout_pad * Kp, __float2half(0.f));
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int r = 0; r < kh; ++r)
+                for (int s = 0; s < kw; ++s)
+                    out[(size_t)o * Kp + (size_t)(r * kw + s) * cin_pad + c] =
+                        __float2half(w[(((size_t)o * cin + c) * kh + r) * kw + s]);
+}
+
+}  // namespace rmr

@@ -1,0 +1,287 @@
+// detector.cpp -- Detector and RobotDetector back ends (src/detect/detector.cpp:48-161,
+// 377-455; src/detect/detector.cu:380-582).  Per call: ONE letterbox launch for the whole batch,
+// the network, ONE decode+NMS+restore launch, one small D2H -- instead of the reference's
+// 3 + 3 launches, one stream and one 202 KB D2H per image.
+#include "detector.h"
+
+#include <cstdlib>
+
+#include "postprocess.h"
+#include "robot.h"
+
+namespace rmr {
+
+// ---- FrameStage ------------------------------------------------------------------------------------
+
+const std::vector<FrameStage::Frame>& FrameStage::stage(hipStream_t s, const rmr_image* imgs, int n) {
+    frames_.resize(n);
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        const rmr_image& im = imgs[i];
+        if (!im.data || im.width <= 0 || im.height <= 0 || im.stride < im.width * 3)
+            fail(RMR_ERR_INVALID_ARGUMENT, "image %d: bad data/size/stride", i);
+        if (im.mem != RMR_MEM_DEVICE) need += ((size_t)im.stride * im.height + 255) & ~(size_t)255;
+    }
+    if (need > dev_.n) {
+        RMR_HIP(hipStreamSynchronize(s));
+        dev_.alloc(need);
+        pin_.alloc(need);
+    }
+    size_t off = 0;
+    bool any_host = false;
+    for (int i = 0; i < n; ++i) {
+        const rmr_image& im = imgs[i];
+        Frame& f = frames_[i];
+        f.width = im.width;
+        f.height = im.height;
+        f.stride = im.stride;
+        if (im.mem == RMR_MEM_DEVICE) {
+            f.dev = im.data;
+            continue;
+        }
+        if (!any_host) {
+            // the pinned buffer is reused across calls: the previous upload must have landed
+            RMR_HIP(hipStreamSynchronize(s));
+            any_host = true;
+        }
+        const size_t bytes = (size_t)im.stride * im.height;
+        std::memcpy(pin_.p + off, im.data, bytes);  // detector.cu:388: memcpy into pinned memory
+        f.dev = dev_.p + off;
+        off += (bytes + 255) & ~(size_t)255;
+    }
+    if (off) RMR_HIP(hipMemcpyAsync(dev_.p, pin_.p, off, hipMemcpyHostToDevice, s));
+    return frames_;
+}
+
+// ---- Detector -----------------------------------------------------------------------------------------
+
+// Detector::Detector (detector.cpp:48-149)
+Detector::Detector(const rmr_detector_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg.device)), stage_(ctx_) {
+    if (!cfg.engine_path || !*cfg.engine_path) fail(RMR_ERR_INVALID_ARGUMENT, "Detector: engine_path is empty");
+    if (cfg.classes <= 0) fail(RMR_ERR_INVALID_ARGUMENT, "Detector: classes must be positive");
+    if (cfg.max_batch_size < 1) fail(RMR_ERR_INVALID_ARGUMENT, "Detector: max_batch_size must be >= 1");
+    if (cfg.input_channels != 3) fail(RMR_ERR_INVALID_ARGUMENT, "Detector: only 3-channel BGR input is supported");
+    if (const char* e = std::getenv("RMR_DET_CAP")) det_cap_ = std::max(16, std::atoi(e));
+    RMR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    net_ = std::make_unique<Yolov8>(ctx_, cfg.engine_path, cfg.classes, cfg.input_width, cfg.input_height,
+                                    cfg.max_batch_size);
+    const int B = cfg.max_batch_size;
+    descs_dev_.alloc(B);
+    pp_dev_.alloc(B);
+    descs_pin_.alloc(B);
+    pp_pin_.alloc(B);
+    post_scratch_.alloc(postprocess_scratch_bytes(B, net_->anchors()));
+    dets_dev_.alloc((size_t)B * det_cap_);
+    dets_pin_.alloc((size_t)B * det_cap_);
+    counts_dev_.alloc(B);
+    counts_pin_.alloc(B);
+}
+
+Detector::~Detector() {
+    if (stream_) {
+        (void)hipStreamSynchronize(stream_);
+        (void)hipStreamDestroy(stream_);
+    }
+}
+
+// preprocess (detector.cu:380-502) + enqueueV3 (detector.h:122) + the device half of
+// postprocess (detector.cu:522-555), all on one stream, no host synchronisation inside
+void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
+    const int n = (int)descs.size();
+    if (n > cfg_.max_batch_size)
+        fail(RMR_ERR_CAPACITY, "Detector: batch of %d exceeds max_batch_size %d", n, cfg_.max_batch_size);
+    ctx_.use();
+    // the pinned descriptor block is reused: make sure the previous call's copy is done
+    RMR_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < n; ++i) {
+        LetterboxDesc& d = descs[i];
+        const rmr_preparam p = make_preparam(d.crop_w, d.crop_h, cfg_.input_width, cfg_.input_height);
+        letterbox_geometry(p, d.rw, d.rh, d.top, d.left);
+        descs_pin_.p[i] = d;
+        pp_pin_.p[i] = p;
+    }
+    RMR_HIP(hipMemcpyAsync(descs_dev_.p, descs_pin_.p, n * sizeof(LetterboxDesc), hipMemcpyHostToDevice, stream_));
+    RMR_HIP(hipMemcpyAsync(pp_dev_.p, pp_pin_.p, n * sizeof(rmr_preparam), hipMemcpyHostToDevice, stream_));
+    launch_letterbox(ctx_, stream_, descs_dev_.p, n, cfg_.input_width, cfg_.input_height, 128, 1 / 255.f,
+                     LB_F16_NHWC8, net_->input());
+    net_->forward(stream_, n);
+    if (!post) return;
+    launch_postprocess(ctx_, stream_, net_->output(), n, net_->channels(), net_->anchors(), net_->nc(),
+                       cfg_.nms_thresh, cfg_.conf_thresh, pp_dev_.p, post_scratch_.p, dets_dev_.p,
+                       counts_dev_.p, det_cap_);
+    RMR_HIP(hipMemcpyAsync(counts_pin_.p, counts_dev_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipMemcpyAsync(dets_pin_.p, dets_dev_.p, (size_t)n * det_cap_ * sizeof(rmr_detection),
+                           hipMemcpyDeviceToHost, stream_));
+}
+
+void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out) {
+    const int n = (int)descs.size();
+    out.assign(n, {});
+    if (n == 0) return;  // Q10d: the reference would abort on an empty batch; return nothing
+    enqueue(descs, true);
+    RMR_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < n; ++i) {
+        const int c = counts_pin_.p[i];
+        if (c > det_cap_)
+            fail(RMR_ERR_CAPACITY, "Detector: image %d produced %d detections (internal cap %d; set RMR_DET_CAP)", i, c, det_cap_);
+        out[i].assign(dets_pin_.p + (size_t)i * det_cap_, dets_pin_.p + (size_t)i * det_cap_ + c);
+    }
+}
+
+static void fill_descs(const std::vector<FrameStage::Frame>& fr, const int* crops, std::vector<LetterboxDesc>& descs) {
+    const int n = (int)fr.size();
+    descs.resize(n);
+    for (int i = 0; i < n; ++i) {
+        LetterboxDesc& d = descs[i];
+        d.src = fr[i].dev;
+        d.src_stride = fr[i].stride;
+        d.crop_x = crops ? crops[4 * i + 0] : 0;
+        d.crop_y = crops ? crops[4 * i + 1] : 0;
+        d.crop_w = crops ? crops[4 * i + 2] : fr[i].width;
+        d.crop_h = crops ? crops[4 * i + 3] : fr[i].height;
+        if (d.crop_x < 0 || d.crop_y < 0 || d.crop_w <= 0 || d.crop_h <= 0 || d.crop_x + d.crop_w > fr[i].width ||
+            d.crop_y + d.crop_h > fr[i].height)
+            fail(RMR_ERR_INVALID_ARGUMENT, "image %d: crop outside the image", i);
+    }
+}
+
+void Detector::detect(const rmr_image* imgs, const int* crops, int n, rmr_detection* out, int* counts, int cap) {
+    if (n < 0 || (n > 0 && (!imgs || !out || !counts)) || cap <= 0)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Detector::detect: bad arguments");
+    ctx_.use();
+    std::vector<LetterboxDesc> descs;
+    fill_descs(stage_.stage(stream_, imgs, n), crops, descs);
+    std::vector<std::vector<rmr_detection>> res;
+    detect_staged(descs, res);
+    bool over = false;
+    for (int i = 0; i < n; ++i) {
+        counts[i] = (int)res[i].size();
+        const int m = std::min(counts[i], cap);
+        std::copy(res[i].begin(), res[i].begin() + m, out + (size_t)i * cap);
+        over |= counts[i] > cap;
+    }
+    if (over) fail(RMR_ERR_CAPACITY, "Detector::detect: more detections than the caller's cap %d", cap);
+}
+
+void Detector::infer(const rmr_image* imgs, const int* crops, int n, float* net_out, rmr_preparam* pp) {
+    if (n <= 0 || !imgs || !net_out) fail(RMR_ERR_INVALID_ARGUMENT, "Detector::infer: bad arguments");
+    ctx_.use();
+    std::vector<LetterboxDesc> descs;
+    fill_descs(stage_.stage(stream_, imgs, n), crops, descs);
+    enqueue(descs, false);
+    RMR_HIP(hipMemcpyAsync(net_out, net_->output(), (size_t)n * net_->channels() * net_->anchors() * sizeof(float),
+                           hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+    if (pp)
+        for (int i = 0; i < n; ++i) pp[i] = pp_pin_.p[i];
+}
+
+// ---- RobotDetector -------------------------------------------------------------------------------------
+
+static rmr_detector_cfg sub_cfg(const rmr_robot_detector_cfg& c, const char* path, int classes, int max_batch,
+                                float nms, float conf) {
+    rmr_detector_cfg d{};
+    d.engine_path = path;
+    d.classes = classes;
+    d.image_width = c.image_width;
+    d.image_height = c.image_height;
+    d.max_batch_size = max_batch;
+    d.opt_batch_size = 0;
+    d.nms_thresh = nms;
+    d.conf_thresh = conf;
+    d.input_width = c.input_width;
+    d.input_height = c.input_height;
+    d.input_channels = c.input_channels;
+    d.device = c.device;
+    return d;
+}
+
+// RobotDetector::RobotDetector (detector.cpp:377-397): the car detector has 1 class and
+// batch 1 (per frame); the armor detector is batched over the cars
+RobotDetector::RobotDetector(const rmr_robot_detector_cfg& cfg)
+    : cfg_(cfg), stage_(device_ctx(cfg.device)) {
+    if (cfg.max_cars < 1) fail(RMR_ERR_INVALID_ARGUMENT, "RobotDetector: max_cars must be >= 1");
+    if (cfg_.max_frames < 1) cfg_.max_frames = 1;
+    car_ = std::make_unique<Detector>(sub_cfg(cfg, cfg.car_engine_path, 1, cfg_.max_frames, cfg.car_nms_thresh, cfg.car_conf_thresh));
+    armor_ = std::make_unique<Detector>(sub_cfg(cfg, cfg.armor_engine_path, cfg.armor_classes,
+                                                 cfg_.max_frames * cfg.max_cars, cfg.armor_nms_thresh,
+                                                 cfg.armor_conf_thresh));
+}
+
+// RobotDetector::detect (detector.cpp:413-455) for n_frames independent frames
+void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int* forced_crops, int forced_per_frame,
+                                 rmr_robot* out, int* n_out, int cap) {
+    if (n_frames <= 0 || !imgs || !out || !n_out || cap <= 0)
+        fail(RMR_ERR_INVALID_ARGUMENT, "RobotDetector::detect: bad arguments");
+    if (n_frames > cfg_.max_frames)
+        fail(RMR_ERR_CAPACITY, "RobotDetector::detect: %d frames exceed max_frames %d", n_frames, cfg_.max_frames);
+    if (forced_crops && (forced_per_frame < 0 || forced_per_frame > cfg_.max_cars))
+        fail(RMR_ERR_INVALID_ARGUMENT, "RobotDetector::detect: forced_per_frame must be in 0..max_cars");
+    car_->ctx().use();
+    const auto& frames = stage_.stage(car_->stream(), imgs, n_frames);
+
+    // stage 1: cars on the full frames (detector.cpp:415)
+    std::vector<LetterboxDesc> descs;
+    fill_descs(frames, nullptr, descs);
+    std::vector<std::vector<rmr_detection>> cars;
+    car_->detect_staged(descs, cars);
+
+    if (forced_crops) {
+        // throughput benches with synthetic weights: the car stage ran in full, but the crops
+        // handed to the armor stage are the caller's
+        for (int f = 0; f < n_frames; ++f) {
+            cars[f].clear();
+            for (int k = 0; k < forced_per_frame; ++k) {
+                const int* r = forced_crops + ((size_t)f * forced_per_frame + k) * 4;
+                cars[f].push_back(rmr_detection{(float)r[0], (float)r[1], (float)r[2], (float)r[3], 0.f, 1.f});
+            }
+        }
+    }
+
+    // stage 2: one armor batch over every car crop of every frame (detector.cpp:417-425)
+    descs.clear();
+    std::vector<int> slot_of;  // per (frame, car): index into the armor batch or -1
+    for (int f = 0; f < n_frames; ++f) {
+        if ((int)cars[f].size() > cfg_.max_cars) cars[f].resize(cfg_.max_cars);  // Q10d
+        for (const rmr_detection& c : cars[f]) {
+            // cv::Rect(x, y, w, h) from floats truncates (detector.cpp:420-421)
+            const int x = (int)c.x, y = (int)c.y, w = (int)c.width, h = (int)c.height;
+            if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > frames[f].width || y + h > frames[f].height) {
+                slot_of.push_back(-1);  // Q10d: empty crop -> no armor batch entry
+                continue;
+            }
+            LetterboxDesc d{};
+            d.src = frames[f].dev;
+            d.src_stride = frames[f].stride;
+            d.crop_x = x;
+            d.crop_y = y;
+            d.crop_w = w;
+            d.crop_h = h;
+            slot_of.push_back((int)descs.size());
+            descs.push_back(d);
+        }
+    }
+    std::vector<std::vector<rmr_detection>> armors;
+    armor_->detect_staged(descs, armors);
+
+    // Robot assembly + per-label de-duplication (detector.cpp:427-454)
+    size_t k = 0;
+    bool over = false;
+    for (int f = 0; f < n_frames; ++f) {
+        std::vector<rmr_robot> robots(cars[f].size());
+        for (size_t i = 0; i < cars[f].size(); ++i, ++k) {
+            const int s = slot_of[k];
+            static const std::vector<rmr_detection> none;
+            const auto& a = s >= 0 ? armors[s] : none;
+            robot_set_detection(robots[i], cars[f][i], a.data(), (int)a.size());
+        }
+        const auto grouped = group_robots(robots.data(), (int)robots.size(), cfg_.iou_thresh);
+        n_out[f] = (int)grouped.size();
+        const int m = std::min(n_out[f], cap);
+        std::copy(grouped.begin(), grouped.begin() + m, out + (size_t)f * cap);
+        over |= n_out[f] > cap;
+    }
+    if (over) fail(RMR_ERR_CAPACITY, "RobotDetector::detect: more robots than the caller's cap %d", cap);
+}
+
+}  // namespace rmr

@@ -1,0 +1,80 @@
+// detector.h -- Detector and RobotDetector back ends (src/detect/detector.h:84-190).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "preprocess.h"
+#include "yolov8.h"
+
+namespace rmr {
+
+// Keeps device copies of host frames for the duration of one detect call.
+class FrameStage {
+   public:
+    explicit FrameStage(DeviceCtx& ctx) : ctx_(ctx) {}
+    // returns, per image, a device pointer + geometry (device images pass through)
+    struct Frame {
+        const uint8_t* dev;
+        int width, height, stride;
+    };
+    const std::vector<Frame>& stage(hipStream_t s, const rmr_image* imgs, int n);
+
+   private:
+    DeviceCtx& ctx_;
+    DevBuf<uint8_t> dev_;
+    PinnedBuf<uint8_t> pin_;
+    std::vector<Frame> frames_;
+};
+
+class Detector {
+   public:
+    explicit Detector(const rmr_detector_cfg& cfg);
+    ~Detector();
+
+    // Detector::detect<T> (detector.h:117-134)
+    void detect(const rmr_image* imgs, const int* crops, int n, rmr_detection* out, int* counts, int cap);
+    void infer(const rmr_image* imgs, const int* crops, int n, float* net_out, rmr_preparam* pp);
+
+    // the same on frames already resident on the device; descs carry src/crop only
+    void detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out);
+
+    Yolov8& net() { return *net_; }
+    hipStream_t stream() { return stream_; }
+    DeviceCtx& ctx() { return ctx_; }
+    int max_batch() const { return cfg_.max_batch_size; }
+
+   private:
+    void enqueue(std::vector<LetterboxDesc>& descs, bool post);
+
+    rmr_detector_cfg cfg_;
+    DeviceCtx& ctx_;
+    hipStream_t stream_ = nullptr;
+    std::unique_ptr<Yolov8> net_;
+    FrameStage stage_;
+    int det_cap_ = 512;
+    DevBuf<LetterboxDesc> descs_dev_;
+    DevBuf<rmr_preparam> pp_dev_;
+    DevBuf<uint8_t> post_scratch_;
+    DevBuf<rmr_detection> dets_dev_;
+    DevBuf<int> counts_dev_;
+    PinnedBuf<LetterboxDesc> descs_pin_;
+    PinnedBuf<rmr_preparam> pp_pin_;
+    PinnedBuf<rmr_detection> dets_pin_;
+    PinnedBuf<int> counts_pin_;
+};
+
+class RobotDetector {
+   public:
+    explicit RobotDetector(const rmr_robot_detector_cfg& cfg);
+    // RobotDetector::detect (detector.cpp:413-455), batched over frames
+    void detect_batch(const rmr_image* imgs, int n_frames, const int* forced_crops, int forced_per_frame,
+                      rmr_robot* out, int* n_out, int cap);
+
+   private:
+    rmr_robot_detector_cfg cfg_;
+    std::unique_ptr<Detector> car_, armor_;
+    FrameStage stage_;
+};
+
+}  // namespace rmr

@@ -1,0 +1,28 @@
+// net_ops.h -- the non-GEMM layers of YOLOv8 on NHWC f16 views: SPPF max-pools, nearest 2x
+// upsample into a concat slice, and the Detect head's DFL + dist2bbox + sigmoid.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace rmr {
+
+// SPPF (Ultralytics nn/modules/block.py): y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) with
+// MaxPool2d(5,1,2).  buf is [N][H][W][cs]; x lives at channels [co, co+C); y1,y2,y3 are written
+// at [co+C, co+2C), [co+2C, co+3C), [co+3C, co+4C).  C % 8 == 0.
+void launch_sppf_pools(DeviceCtx& ctx, hipStream_t s, __half* buf, int N, int H, int W, int cs,
+                       int co, int C);
+
+// nearest-neighbour 2x upsample of src view [N][H][W][C] into dst view [N][2H][2W][C]
+void launch_upsample2x(DeviceCtx& ctx, hipStream_t s, const __half* src, int src_cs, int src_co,
+                       __half* dst, int dst_cs, int dst_co, int N, int H, int W, int C);
+
+// Detect inference form (Ultralytics nn/modules/head.py): for every anchor of one scale,
+// DFL softmax-expectation over 16 bins x 4 sides, dist2bbox -> cx,cy,w,h times stride, class
+// sigmoid.  box: f32 [N][H*W][64]; cls: f32 [N][H*W][cls_cs]; out: f32 [N][4+nc][A_total],
+// this scale's anchors start at a_off.
+void launch_head_decode(DeviceCtx& ctx, hipStream_t s, const float* box, const float* cls,
+                        int cls_cs, int nc, float* out, int N, int H, int W, int stride,
+                        int a_off, int a_total);
+
+}  // namespace rmr

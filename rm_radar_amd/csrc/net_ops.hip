@@ -1,0 +1,149 @@
+// net_ops.hip -- see net_ops.h.  All three are HBM/L2-bound elementwise passes: 16-byte
+// (8 x f16) accesses per lane, channels fastest so a wave touches contiguous lines.
+#include "net_ops.h"
+
+namespace rmr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
+    half8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
+    return r;
+}
+
+// One thread = one pixel x 8 channels.  Three chained 5x5 pools == windows of radius 2, 4, 6
+// (max is idempotent and -inf padding just shrinks the window), computed in one sweep of the
+// 13x13 neighbourhood so x is read once from L2 instead of three dependent passes.
+__global__ __launch_bounds__(256) void sppf_pools_kernel(__half* __restrict__ buf, int N, int H,
+                                                         int W, int cs, int co, int C) {
+    const int cg = C / 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * H * W * cg;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    long t = idx / cg;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const _Float16 ninf = (_Float16)(-65504.0f);
+    half8 m1, m2, m3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m1[i] = m2[i] = m3[i] = ninf;
+    const _Float16* base = (const _Float16*)buf + ((long)n * H * W) * cs + co + g * 8;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const int ady = dy < 0 ? -dy : dy;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const int adx = dx < 0 ? -dx : dx;
+            const int r = ady > adx ? ady : adx;
+            const half8 v = *(const half8*)(base + ((long)yy * W + xx) * cs);
+            m3 = hmax8(m3, v);
+            if (r <= 4) m2 = hmax8(m2, v);
+            if (r <= 2) m1 = hmax8(m1, v);
+        }
+    }
+    _Float16* o = (_Float16*)buf + (((long)n * H + y) * W + x) * cs + co + g * 8;
+    *(half8*)(o + C) = m1;
+    *(half8*)(o + 2 * C) = m2;
+    *(half8*)(o + 3 * C) = m3;
+}
+
+void launch_sppf_pools(DeviceCtx& ctx, hipStream_t s, __half* buf, int N, int H, int W, int cs,
+                       int co, int C) {
+    const long total = (long)N * H * W * (C / 8);
+    ProfScope ps(ctx.prof, s, "sppf_pools", 0, (double)total * 16 * 4);
+    sppf_pools_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(buf, N, H, W, cs, co, C);
+    RMR_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(const __half* __restrict__ src, int src_cs,
+                                                         int src_co, __half* __restrict__ dst,
+                                                         int dst_cs, int dst_co, int N, int H, int W,
+                                                         int C) {
+    const int cg = C / 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * 2 * H * 2 * W * cg;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    long t = idx / cg;
+    const int x = (int)(t % (2 * W));
+    t /= 2 * W;
+    const int y = (int)(t % (2 * H));
+    const int n = (int)(t / (2 * H));
+    const uint4 v = *(const uint4*)((const _Float16*)src + (((long)n * H + (y >> 1)) * W + (x >> 1)) * src_cs + src_co + g * 8);
+    *(uint4*)((_Float16*)dst + (((long)n * 2 * H + y) * 2 * W + x) * dst_cs + dst_co + g * 8) = v;
+}
+
+void launch_upsample2x(DeviceCtx& ctx, hipStream_t s, const __half* src, int src_cs, int src_co,
+                       __half* dst, int dst_cs, int dst_co, int N, int H, int W, int C) {
+    const long total = (long)N * 4 * H * W * (C / 8);
+    ProfScope ps(ctx.prof, s, "upsample2x", 0, (double)total * 16 * 1.25);
+    upsample2x_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(src, src_cs, src_co, dst, dst_cs, dst_co, N, H, W, C);
+    RMR_HIP(hipGetLastError());
+}
+
+// One thread per anchor.  Reads 64 + nc f32 logits (the anchor's row is contiguous: 256 B),
+// writes 4 + nc f32 into the [C][A] planes (coalesced across the anchors of a wave).
+__global__ __launch_bounds__(256) void head_decode_kernel(const float* __restrict__ box,
+                                                          const float* __restrict__ cls, int cls_cs,
+                                                          int nc, float* __restrict__ out, int N,
+                                                          int H, int W, int stride, int a_off,
+                                                          int a_total) {
+    const int hw = H * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * hw) return;
+    const int n = (int)(idx / hw);
+    const int a = (int)(idx % hw);
+    const float* b = box + idx * 64;
+    float dist[4];
+#pragma unroll
+    for (int side = 0; side < 4; ++side) {
+        float v[16];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = *(const float4*)(b + side * 16 + q * 4);
+            v[q * 4 + 0] = t.x;
+            v[q * 4 + 1] = t.y;
+            v[q * 4 + 2] = t.z;
+            v[q * 4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, v[i]);
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __expf(v[i] - mx);
+            se += e;
+            sw += e * (float)i;
+        }
+        dist[side] = sw / se;
+    }
+    const float ax = (float)(a % W) + 0.5f, ay = (float)(a / W) + 0.5f;
+    const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+    const float st = (float)stride;
+    float* o = out + (long)n * (4 + nc) * a_total + a_off + a;
+    o[0] = (x1 + x2) * 0.5f * st;
+    o[(long)a_total] = (y1 + y2) * 0.5f * st;
+    o[(long)2 * a_total] = (x2 - x1) * st;
+    o[(long)3 * a_total] = (y2 - y1) * st;
+    const float* c = cls + idx * cls_cs;
+    for (int j = 0; j < nc; ++j) o[(long)(4 + j) * a_total] = 1.0f / (1.0f + __expf(-c[j]));
+}
+
+void launch_head_decode(DeviceCtx& ctx, hipStream_t s, const float* box, const float* cls,
+                        int cls_cs, int nc, float* out, int N, int H, int W, int stride,
+                        int a_off, int a_total) {
+    const long total = (long)N * H * W;
+    ProfScope ps(ctx.prof, s, "head_decode", 0, (double)total * (64 + cls_cs + 4 + nc) * 4);
+    head_decode_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(box, cls, cls_cs, nc, out, N, H, W, stride, a_off, a_total);
+    RMR_HIP(hipGetLastError());
+}
+
+}  // namespace rmr

@@ -1,0 +1,96 @@
+// yolov8.h -- the network behind Detector: what the reference delegates to a TensorRT engine
+// built from car.onnx / armor.onnx (src/detect/detector.cpp:177-243, detector.h:122).
+// Public Ultralytics YOLOv8 architecture executed as a flat list of
+// strided-view ops on one activation arena; weights come from a *.rmrw pack.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "conv_igemm.h"
+
+namespace rmr {
+
+struct WeightPack {
+    float depth = 0, width = 0;
+    unsigned max_ch = 0, nc = 0, reg_max = 16;
+    struct Tensor {
+        std::vector<unsigned> dims;
+        std::vector<float> data;
+    };
+    std::map<std::string, Tensor> tensors;
+    static WeightPack load(const std::string& path);
+    const Tensor& get(const std::string& name) const;
+};
+
+// A strided NHWC view into the arena: element offset of the buffer for image 0, elements per
+// pixel, first channel, channels, spatial size.
+struct View {
+    size_t off = 0;  // in halves (or floats for f32 buffers), per-chunk buffer start
+    int cs = 0, co = 0, c = 0, h = 0, w = 0;
+};
+
+class Yolov8 {
+   public:
+    // in_w/in_h: network input size (multiples of 32); max_batch: largest forward() batch
+    Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int in_w, int in_h,
+           int max_batch);
+
+    int nc() const { return nc_; }
+    int anchors() const { return anchors_; }
+    int channels() const { return 4 + nc_; }
+    double flops_per_image() const { return flops_; }
+    int max_batch() const { return max_batch_; }
+
+    // network input: f16 NHWC with 8 channels per pixel (RGB + 5 zero lanes), [max_batch]
+    __half* input() { return input_.p; }
+    // network output: f32 [batch][4+nc][anchors], the tensor TensorRT hands to postprocess
+    float* output() { return output_.p; }
+    void forward(hipStream_t s, int batch);
+
+   private:
+    enum OpKind { OP_CONV, OP_SPPF, OP_UP, OP_HEAD };
+    struct ConvW {
+        DevBuf<__half> w;
+        DevBuf<float> b;
+        int cout = 0, cout_pad = 0, cin = 0, k = 0, K = 0, Kp = 0;
+    };
+    struct Op {
+        OpKind kind;
+        int conv = -1;      // index into convs_
+        View in, out, res;  // res.c == 0 : none
+        bool in_is_input = false;
+        bool out_f32 = false;
+        int stride = 1, act = 1;
+        // OP_HEAD
+        View box, cls;
+        int head_stride = 0, a_off = 0;
+    };
+
+    View alloc(int h, int w, int c, bool f32 = false);
+    static View slice(const View& v, int co, int c);
+    int add_conv_weights(const WeightPack& p, const std::string& name, int cin_pad);
+    int add_fused_head_weights(const WeightPack& p, const std::string& a, const std::string& b);
+    void conv(int widx, const View& in, const View& out, int stride, int act, const View* res = nullptr,
+              bool out_f32 = false, bool in_is_input = false);
+    View c2f(const WeightPack& p, const std::string& name, const View& x, int n, bool shortcut,
+             const View* out_view);
+    void run_op(hipStream_t s, const Op& op, int chunk_n, size_t img_base);
+
+    DeviceCtx& ctx_;
+    int nc_, in_w_, in_h_, max_batch_, chunk_;
+    int anchors_ = 0;
+    double flops_ = 0;
+    std::vector<ConvW> convs_;
+    std::vector<Op> ops_;
+    size_t arena_halves_ = 0, arena_floats_ = 0;  // per image
+    DevBuf<__half> arena_;
+    DevBuf<float> arena32_;
+    DevBuf<__half> input_;
+    DevBuf<float> output_;
+};
+
+}  // namespace rmr

@@ -1,0 +1,381 @@
+// yolov8.hip -- weight-pack loader, graph planner and executor for the YOLOv8 detector network
+// (public Ultralytics architecture; replaces the TensorRT engine the
+// reference builds in src/detect/detector.cpp:177-243 and runs at src/detect/detector.h:122).
+//
+// Layout decisions (MI355X-first):
+//  * activations f16 NHWC in one arena; every C2f / SPPF / FPN concat is a wider buffer whose
+//    channel slices are written in place by the producing conv (no concat kernels, no copies
+//    except the two nearest-2x upsamples);
+//  * the Detect head's two first 3x3 convs of a scale share their input, so they run as ONE
+//    implicit GEMM with N = 64 + c3 output channels;
+//  * large batches are walked in chunks so one layer's in+out activations stay within the
+//    256 MiB Infinity Cache instead of streaming the whole batch through HBM per layer.
+#include "yolov8.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+
+#include "net_ops.h"
+
+namespace rmr {
+
+// ---- weight pack ---------------------------------------------------------------------------------
+
+WeightPack WeightPack::load(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail(RMR_ERR_INVALID_ARGUMENT, "weight pack '%s' does not exist or cannot be opened", path.c_str());
+    auto rd = [&](void* p, size_t n) {
+        f.read((char*)p, (std::streamsize)n);
+        if (!f) fail(RMR_ERR_RUNTIME, "weight pack '%s' is truncated", path.c_str());
+    };
+    char magic[4];
+    rd(magic, 4);
+    if (std::memcmp(magic, "RMRW", 4) != 0) fail(RMR_ERR_RUNTIME, "'%s' is not an RMRW weight pack", path.c_str());
+    unsigned version, n;
+    WeightPack p;
+    rd(&version, 4);
+    if (version != 1) fail(RMR_ERR_RUNTIME, "'%s': unsupported pack version %u", path.c_str(), version);
+    rd(&p.depth, 4);
+    rd(&p.width, 4);
+    rd(&p.max_ch, 4);
+    rd(&p.nc, 4);
+    rd(&p.reg_max, 4);
+    rd(&n, 4);
+    for (unsigned i = 0; i < n; ++i) {
+        unsigned ln, nd;
+        rd(&ln, 4);
+        if (ln > 4096) fail(RMR_ERR_RUNTIME, "'%s': corrupt tensor name", path.c_str());
+        std::string name(ln, '\0');
+        rd(&name[0], ln);
+        rd(&nd, 4);
+        if (nd > 8) fail(RMR_ERR_RUNTIME, "'%s': corrupt tensor rank", path.c_str());
+        Tensor t;
+        t.dims.resize(nd);
+        rd(t.dims.data(), 4 * nd);
+        size_t cnt = 1;
+        for (unsigned d : t.dims) cnt *= d;
+        t.data.resize(cnt);
+        rd(t.data.data(), cnt * 4);
+        p.tensors.emplace(std::move(name), std::move(t));
+    }
+    return p;
+}
+
+const WeightPack::Tensor& WeightPack::get(const std::string& name) const {
+    auto it = tensors.find(name);
+    if (it == tensors.end()) fail(RMR_ERR_RUNTIME, "weight pack has no tensor '%s'", name.c_str());
+    return it->second;
+}
+
+// ---- planner ----------------------------------------------------------------------------------------
+
+View Yolov8::alloc(int h, int w, int c, bool f32) {
+    View v;
+    v.cs = c;
+    v.co = 0;
+    v.c = c;
+    v.h = h;
+    v.w = w;
+    size_t& top = f32 ? arena_floats_ : arena_halves_;
+    v.off = top;
+    top += (size_t)h * w * c;
+    top = (top + 63) & ~(size_t)63;
+    return v;
+}
+
+View Yolov8::slice(const View& v, int co, int c) {
+    View s = v;
+    s.co = v.co + co;
+    s.c = c;
+    return s;
+}
+
+int Yolov8::add_conv_weights(const WeightPack& p, const std::string& name, int cin_pad) {
+    const auto& w = p.get(name + ".weight");
+    const auto& b = p.get(name + ".bias");
+    if (w.dims.size() != 4 || w.dims[2] != w.dims[3]) fail(RMR_ERR_RUNTIME, "tensor '%s.weight' is not OIkk", name.c_str());
+    ConvW cw;
+    cw.cout = (int)w.dims[0];
+    cw.cin = cin_pad > 0 ? cin_pad : (int)w.dims[1];
+    cw.k = (int)w.dims[2];
+    cw.cout_pad = (cw.cout + 15) / 16 * 16;
+    if ((int)w.dims[1] > cw.cin || cw.cin % 8)
+        fail(RMR_ERR_RUNTIME, "conv '%s': %u input channels cannot be consumed in 8-channel chunks", name.c_str(), w.dims[1]);
+    if (b.data.size() != (size_t)cw.cout) fail(RMR_ERR_RUNTIME, "tensor '%s.bias' has the wrong size", name.c_str());
+    std::vector<__half> packed;
+    pack_conv_weights(w.data.data(), cw.cout, (int)w.dims[1], cw.k, cw.k, cw.cin, cw.cout_pad, packed, cw.K, cw.Kp);
+    std::vector<float> bias(cw.cout_pad, 0.f);
+    std::copy(b.data.begin(), b.data.end(), bias.begin());
+    cw.w.alloc(packed.size());
+    cw.b.alloc(bias.size());
+    RMR_HIP(hipMemcpy(cw.w.p, packed.data(), packed.size() * sizeof(__half), hipMemcpyHostToDevice));
+    RMR_HIP(hipMemcpy(cw.b.p, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    convs_.push_back(std::move(cw));
+    return (int)convs_.size() - 1;
+}
+
+// two convs over the same input, concatenated along Cout (Detect cv2.i.0 + cv3.i.0)
+int Yolov8::add_fused_head_weights(const WeightPack& p, const std::string& a, const std::string& b) {
+    const auto& wa = p.get(a + ".weight");
+    const auto& wb = p.get(b + ".weight");
+    const auto& ba = p.get(a + ".bias");
+    const auto& bb = p.get(b + ".bias");
+    if (wa.dims.size() != 4 || wb.dims.size() != 4 || wa.dims[1] != wb.dims[1] || wa.dims[2] != wb.dims[2])
+        fail(RMR_ERR_RUNTIME, "cannot fuse '%s' and '%s'", a.c_str(), b.c_str());
+    ConvW cw;
+    cw.cout = (int)(wa.dims[0] + wb.dims[0]);
+    cw.cin = (int)wa.dims[1];
+    cw.k = (int)wa.dims[2];
+    cw.cout_pad = (cw.cout + 15) / 16 * 16;
+    if (cw.cin % 8 || wa.dims[0] % 16) fail(RMR_ERR_RUNTIME, "head conv '%s' has unsupported channel counts", a.c_str());
+    std::vector<float> w(wa.data);
+    w.insert(w.end(), wb.data.begin(), wb.data.end());
+    std::vector<__half> packed;
+    pack_conv_weights(w.data(), cw.cout, cw.cin, cw.k, cw.k, cw.cin, cw.cout_pad, packed, cw.K, cw.Kp);
+    std::vector<float> bias(cw.cout_pad, 0.f);
+    std::copy(ba.data.begin(), ba.data.end(), bias.begin());
+    std::copy(bb.data.begin(), bb.data.end(), bias.begin() + ba.data.size());
+    cw.w.alloc(packed.size());
+    cw.b.alloc(bias.size());
+    RMR_HIP(hipMemcpy(cw.w.p, packed.data(), packed.size() * sizeof(__half), hipMemcpyHostToDevice));
+    RMR_HIP(hipMemcpy(cw.b.p, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    convs_.push_back(std::move(cw));
+    return (int)convs_.size() - 1;
+}
+
+void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act, const View* res,
+                  bool out_f32, bool in_is_input) {
+    const ConvW& cw = convs_[widx];
+    if (in.c != cw.cin) fail(RMR_ERR_LOGIC, "planner: conv %d expects %d input channels, view has %d", widx, cw.cin, in.c);
+    if (out.c != cw.cout_pad && !(out_f32 && out.cs == cw.cout_pad))
+        if (out.c != cw.cout) fail(RMR_ERR_LOGIC, "planner: conv %d produces %d channels, view has %d", widx, cw.cout, out.c);
+    Op op{};
+    op.kind = OP_CONV;
+    op.conv = widx;
+    op.in = in;
+    op.out = out;
+    if (res) op.res = *res;
+    op.stride = stride;
+    op.act = act;
+    op.out_f32 = out_f32;
+    op.in_is_input = in_is_input;
+    ops_.push_back(op);
+    // algorithmic FLOPs: 2*MAC with the pack's true channel counts
+    flops_ += 2.0 * out.h * out.w * (double)cw.cout * (in_is_input ? 3 : cw.cin) * cw.k * cw.k;
+}
+
+// C2f (Ultralytics nn/modules/block.py): cv1 -> split -> n bottlenecks chained on the last
+// half -> cv2 over the (2+n)*c concat.  The concat buffer IS where everything is written.
+View Yolov8::c2f(const WeightPack& p, const std::string& name, const View& x, int n, bool shortcut,
+                 const View* out_view) {
+    const int cout = (int)p.get(name + ".cv2.conv.weight").dims[0];
+    const int c = cout / 2;
+    if (c % 16) fail(RMR_ERR_RUNTIME, "C2f '%s': hidden width %d is not a multiple of 16", name.c_str(), c);
+    View cat = alloc(x.h, x.w, (2 + n) * c);
+    conv(add_conv_weights(p, name + ".cv1.conv", 0), x, slice(cat, 0, 2 * c), 1, 1);
+    for (int i = 0; i < n; ++i) {
+        View tmp = alloc(x.h, x.w, c);
+        const View prev = slice(cat, (1 + i) * c, c);
+        const std::string m = name + ".m." + std::to_string(i);
+        conv(add_conv_weights(p, m + ".cv1.conv", 0), prev, tmp, 1, 1);
+        conv(add_conv_weights(p, m + ".cv2.conv", 0), tmp, slice(cat, (2 + i) * c, c), 1, 1,
+             shortcut ? &prev : nullptr);
+    }
+    View out = out_view ? *out_view : alloc(x.h, x.w, cout);
+    conv(add_conv_weights(p, name + ".cv2.conv", 0), cat, out, 1, 1);
+    return out;
+}
+
+static int make_divisible(double x, int d) { return (int)std::ceil(x / d) * d; }
+
+Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int in_w, int in_h, int max_batch)
+    : ctx_(ctx), in_w_(in_w), in_h_(in_h), max_batch_(max_batch) {
+    if (in_w <= 0 || in_h <= 0 || in_w % 32 || in_h % 32)
+        fail(RMR_ERR_INVALID_ARGUMENT, "network input %dx%d must be a positive multiple of 32", in_w, in_h);
+    if (max_batch < 1) fail(RMR_ERR_INVALID_ARGUMENT, "max_batch_size must be >= 1");
+    ctx.use();
+    const WeightPack p = WeightPack::load(pack_path);
+    nc_ = (int)p.nc;
+    if (expect_nc > 0 && expect_nc != nc_)
+        fail(RMR_ERR_INVALID_ARGUMENT, "weight pack '%s' has %d classes, Detector was given %d", pack_path.c_str(), nc_, expect_nc);
+    if (p.reg_max != 16) fail(RMR_ERR_RUNTIME, "only reg_max = 16 is supported");
+
+    int chunk = 32;
+    if (const char* e = std::getenv("RMR_CHUNK")) chunk = std::max(1, std::atoi(e));
+    chunk_ = std::min(chunk, max_batch);
+
+    int ch[5];
+    const int basech[5] = {64, 128, 256, 512, 1024};
+    for (int i = 0; i < 5; ++i) ch[i] = make_divisible(std::min<double>(basech[i], p.max_ch) * p.width, 8);
+    auto rep = [&](int r) { return std::max((int)std::lround(r * p.depth), 1); };
+    const int n0 = rep(3), n1 = rep(6), n2 = rep(6), n3 = rep(3), nh = rep(3);
+    const int H = in_h, W = in_w;
+
+    View x0;
+    x0.cs = 8;
+    x0.c = 8;
+    x0.h = H;
+    x0.w = W;
+    View l0 = alloc(H / 2, W / 2, ch[0]);
+    conv(add_conv_weights(p, "model.0.conv", 8), x0, l0, 2, 1, nullptr, false, true);
+    View l1 = alloc(H / 4, W / 4, ch[1]);
+    conv(add_conv_weights(p, "model.1.conv", 0), l0, l1, 2, 1);
+    View l2 = c2f(p, "model.2", l1, n0, true, nullptr);
+    View l3 = alloc(H / 8, W / 8, ch[2]);
+    conv(add_conv_weights(p, "model.3.conv", 0), l2, l3, 2, 1);
+    View cat14 = alloc(H / 8, W / 8, ch[3] + ch[2]);  // [up(model.12), model.4]
+    View l4v = slice(cat14, ch[3], ch[2]);
+    View l4 = c2f(p, "model.4", l3, n1, true, &l4v);
+    View l5 = alloc(H / 16, W / 16, ch[3]);
+    conv(add_conv_weights(p, "model.5.conv", 0), l4, l5, 2, 1);
+    View cat11 = alloc(H / 16, W / 16, ch[4] + ch[3]);  // [up(model.9), model.6]
+    View l6v = slice(cat11, ch[4], ch[3]);
+    View l6 = c2f(p, "model.6", l5, n2, true, &l6v);
+    View l7 = alloc(H / 32, W / 32, ch[4]);
+    conv(add_conv_weights(p, "model.7.conv", 0), l6, l7, 2, 1);
+    View l8 = c2f(p, "model.8", l7, n3, true, nullptr);
+    // SPPF
+    const int cs = ch[4] / 2;
+    if (cs % 8) fail(RMR_ERR_RUNTIME, "SPPF hidden width %d is not a multiple of 8", cs);
+    View spp = alloc(H / 32, W / 32, 4 * cs);
+    conv(add_conv_weights(p, "model.9.cv1.conv", 0), l8, slice(spp, 0, cs), 1, 1);
+    {
+        Op op{};
+        op.kind = OP_SPPF;
+        op.in = slice(spp, 0, cs);
+        ops_.push_back(op);
+    }
+    View cat20 = alloc(H / 32, W / 32, ch[3] + ch[4]);  // [model.19, model.9]
+    View l9 = slice(cat20, ch[3], ch[4]);
+    conv(add_conv_weights(p, "model.9.cv2.conv", 0), spp, l9, 1, 1);
+    // neck
+    {
+        Op op{};
+        op.kind = OP_UP;
+        op.in = l9;
+        op.out = slice(cat11, 0, ch[4]);
+        ops_.push_back(op);
+    }
+    View cat17 = alloc(H / 16, W / 16, ch[2] + ch[3]);  // [model.16, model.12]
+    View l12v = slice(cat17, ch[2], ch[3]);
+    View l12 = c2f(p, "model.12", cat11, nh, false, &l12v);
+    {
+        Op op{};
+        op.kind = OP_UP;
+        op.in = l12;
+        op.out = slice(cat14, 0, ch[3]);
+        ops_.push_back(op);
+    }
+    View l15 = c2f(p, "model.15", cat14, nh, false, nullptr);
+    conv(add_conv_weights(p, "model.16.conv", 0), l15, slice(cat17, 0, ch[2]), 2, 1);
+    View l18 = c2f(p, "model.18", cat17, nh, false, nullptr);
+    conv(add_conv_weights(p, "model.19.conv", 0), l18, slice(cat20, 0, ch[3]), 2, 1);
+    View l21 = c2f(p, "model.21", cat20, nh, false, nullptr);
+
+    // Detect
+    const View feats[3] = {l15, l18, l21};
+    const int strides[3] = {8, 16, 32};
+    anchors_ = 0;
+    for (int i = 0; i < 3; ++i) anchors_ += feats[i].h * feats[i].w;
+    int a_off = 0;
+    const int cls_pad = (nc_ + 15) / 16 * 16;
+    for (int i = 0; i < 3; ++i) {
+        const View& f = feats[i];
+        const std::string b = "model.22.cv2." + std::to_string(i), c = "model.22.cv3." + std::to_string(i);
+        const int c2d = (int)p.get(b + ".0.conv.weight").dims[0];
+        const int c3d = (int)p.get(c + ".0.conv.weight").dims[0];
+        View h1 = alloc(f.h, f.w, c2d + c3d);
+        conv(add_fused_head_weights(p, b + ".0.conv", c + ".0.conv"), f, h1, 1, 1);
+        View hb = alloc(f.h, f.w, c2d), hc = alloc(f.h, f.w, c3d);
+        conv(add_conv_weights(p, b + ".1.conv", 0), slice(h1, 0, c2d), hb, 1, 1);
+        conv(add_conv_weights(p, c + ".1.conv", 0), slice(h1, c2d, c3d), hc, 1, 1);
+        View box = alloc(f.h, f.w, 64, true), cls = alloc(f.h, f.w, cls_pad, true);
+        conv(add_conv_weights(p, b + ".2", 0), hb, box, 1, 0, nullptr, true);
+        conv(add_conv_weights(p, c + ".2", 0), hc, cls, 1, 0, nullptr, true);
+        Op op{};
+        op.kind = OP_HEAD;
+        op.box = box;
+        op.cls = cls;
+        op.head_stride = strides[i];
+        op.a_off = a_off;
+        op.in = f;
+        ops_.push_back(op);
+        a_off += f.h * f.w;
+    }
+
+    arena_.alloc(arena_halves_ * chunk_);
+    arena32_.alloc(arena_floats_ * chunk_);
+    input_.alloc((size_t)max_batch_ * H * W * 8);
+    output_.alloc((size_t)max_batch_ * (4 + nc_) * anchors_);
+    RMR_HIP(hipMemset(arena_.p, 0, arena_.n * sizeof(__half)));
+    RMR_HIP(hipMemset(arena32_.p, 0, arena32_.n * sizeof(float)));
+}
+
+// ---- executor ---------------------------------------------------------------------------------------
+
+void Yolov8::run_op(hipStream_t s, const Op& op, int n, size_t img0) {
+    auto hptr = [&](const View& v) { return arena_.p + v.off * chunk_; };
+    auto fptr = [&](const View& v) { return arena32_.p + v.off * chunk_; };
+    switch (op.kind) {
+        case OP_CONV: {
+            const ConvW& cw = convs_[op.conv];
+            ConvArgs a{};
+            a.in = op.in_is_input ? input_.p + img0 * in_h_ * in_w_ * 8 : hptr(op.in);
+            a.in_cs = op.in.cs;
+            a.in_co = op.in.co;
+            a.N = n;
+            a.H = op.in.h;
+            a.W = op.in.w;
+            a.Cin = cw.cin;
+            a.Ho = op.out.h;
+            a.Wo = op.out.w;
+            a.KH = a.KW = cw.k;
+            a.stride = op.stride;
+            a.pad = cw.k / 2;
+            a.wt = cw.w.p;
+            a.bias = cw.b.p;
+            if (op.out_f32)
+                a.out32 = fptr(op.out);
+            else
+                a.out = hptr(op.out);
+            a.out_cs = op.out.cs;
+            a.out_co = op.out.co;
+            if (op.res.c) {
+                a.res = hptr(op.res);
+                a.res_cs = op.res.cs;
+                a.res_co = op.res.co;
+            }
+            a.Cout_pad = cw.cout_pad;
+            a.K = cw.K;
+            a.Kp = cw.Kp;
+            a.M = n * a.Ho * a.Wo;
+            a.act = op.act;
+            a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
+            launch_conv(ctx_, s, a, conv_pick_tile(a.M, a.Cout_pad, ctx_.num_cus));
+            break;
+        }
+        case OP_SPPF:
+            launch_sppf_pools(ctx_, s, hptr(op.in), n, op.in.h, op.in.w, op.in.cs, op.in.co, op.in.c);
+            break;
+        case OP_UP:
+            launch_upsample2x(ctx_, s, hptr(op.in), op.in.cs, op.in.co, hptr(op.out), op.out.cs, op.out.co, n,
+                              op.in.h, op.in.w, op.in.c);
+            break;
+        case OP_HEAD:
+            launch_head_decode(ctx_, s, fptr(op.box), fptr(op.cls), op.cls.cs, nc_,
+                               output_.p + img0 * (size_t)(4 + nc_) * anchors_, n, op.in.h, op.in.w,
+                               op.head_stride, op.a_off, anchors_);
+            break;
+    }
+}
+
+void Yolov8::forward(hipStream_t s, int batch) {
+    if (batch < 0 || batch > max_batch_) fail(RMR_ERR_CAPACITY, "forward: batch %d exceeds max_batch_size %d", batch, max_batch_);
+    for (int c0 = 0; c0 < batch; c0 += chunk_) {
+        const int n = std::min(chunk_, batch - c0);
+        for (const Op& op : ops_) run_op(s, op, n, (size_t)c0);
+    }
+}
+
+}  // namespace rmr

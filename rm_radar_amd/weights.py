@@ -32,6 +32,95 @@ SCALES = {  # depth, width, max_channels  (Ultralytics yolov8.yaml)
 }
 
 
+# per-layer gains from tools/calibrate_gains.py (scale m): unit post-activation std on
+# uniform-noise input, DFL / class logits std 1.5
+GAINS = {
+    "model.0.conv": 6.4100,
+    "model.1.conv": 2.7809,
+    "model.2.cv1.conv": 2.6302,
+    "model.2.m.0.cv1.conv": 2.1683,
+    "model.2.m.0.cv2.conv": 1.5554,
+    "model.2.m.1.cv1.conv": 1.2707,
+    "model.2.m.1.cv2.conv": 3.4144,
+    "model.2.cv2.conv": 1.2325,
+    "model.3.conv": 2.6666,
+    "model.4.cv1.conv": 2.4678,
+    "model.4.m.0.cv1.conv": 1.7147,
+    "model.4.m.0.cv2.conv": 2.1494,
+    "model.4.m.1.cv1.conv": 0.9212,
+    "model.4.m.1.cv2.conv": 2.9039,
+    "model.4.m.2.cv1.conv": 0.4809,
+    "model.4.m.2.cv2.conv": 2.9984,
+    "model.4.m.3.cv1.conv": 0.3793,
+    "model.4.m.3.cv2.conv": 2.0271,
+    "model.4.cv2.conv": 0.5495,
+    "model.5.conv": 2.2836,
+    "model.6.cv1.conv": 2.4788,
+    "model.6.m.0.cv1.conv": 2.5806,
+    "model.6.m.0.cv2.conv": 2.4972,
+    "model.6.m.1.cv1.conv": 1.2623,
+    "model.6.m.1.cv2.conv": 2.4345,
+    "model.6.m.2.cv1.conv": 0.6771,
+    "model.6.m.2.cv2.conv": 1.4707,
+    "model.6.m.3.cv1.conv": 0.3609,
+    "model.6.m.3.cv2.conv": 2.6934,
+    "model.6.cv2.conv": 0.6092,
+    "model.7.conv": 2.5893,
+    "model.8.cv1.conv": 2.2062,
+    "model.8.m.0.cv1.conv": 2.3131,
+    "model.8.m.0.cv2.conv": 2.2198,
+    "model.8.m.1.cv1.conv": 0.9845,
+    "model.8.m.1.cv2.conv": 2.3081,
+    "model.8.cv2.conv": 1.1839,
+    "model.9.cv1.conv": 1.9736,
+    "model.9.cv2.conv": 0.7673,
+    "model.12.cv1.conv": 2.4986,
+    "model.12.m.0.cv1.conv": 3.4060,
+    "model.12.m.0.cv2.conv": 2.3840,
+    "model.12.m.1.cv1.conv": 1.6709,
+    "model.12.m.1.cv2.conv": 2.6329,
+    "model.12.cv2.conv": 2.1522,
+    "model.15.cv1.conv": 2.0205,
+    "model.15.m.0.cv1.conv": 2.6658,
+    "model.15.m.0.cv2.conv": 2.3408,
+    "model.15.m.1.cv1.conv": 2.5392,
+    "model.15.m.1.cv2.conv": 2.8400,
+    "model.15.cv2.conv": 2.2024,
+    "model.16.conv": 3.1060,
+    "model.18.cv1.conv": 2.2553,
+    "model.18.m.0.cv1.conv": 2.7363,
+    "model.18.m.0.cv2.conv": 2.7115,
+    "model.18.m.1.cv1.conv": 3.0334,
+    "model.18.m.1.cv2.conv": 2.4263,
+    "model.18.cv2.conv": 1.9924,
+    "model.19.conv": 2.1215,
+    "model.21.cv1.conv": 2.3141,
+    "model.21.m.0.cv1.conv": 2.6069,
+    "model.21.m.0.cv2.conv": 2.2370,
+    "model.21.m.1.cv1.conv": 2.4912,
+    "model.21.m.1.cv2.conv": 2.3012,
+    "model.21.cv2.conv": 2.3504,
+    "model.22.cv2.0.0.conv": 2.1290,
+    "model.22.cv2.0.1.conv": 2.4702,
+    "model.22.cv2.0.2": 1.7611,
+    "model.22.cv3.0.0.conv": 2.5598,
+    "model.22.cv3.0.1.conv": 2.8013,
+    "model.22.cv3.0.2": 3.0202,
+    "model.22.cv2.1.0.conv": 2.1334,
+    "model.22.cv2.1.1.conv": 1.8237,
+    "model.22.cv2.1.2": 2.5475,
+    "model.22.cv3.1.0.conv": 3.1193,
+    "model.22.cv3.1.1.conv": 2.3806,
+    "model.22.cv3.1.2": 2.5850,
+    "model.22.cv2.2.0.conv": 2.7514,
+    "model.22.cv2.2.1.conv": 2.3615,
+    "model.22.cv2.2.2": 2.1993,
+    "model.22.cv3.2.0.conv": 2.6506,
+    "model.22.cv3.2.1.conv": 2.2883,
+    "model.22.cv3.2.2": 3.7046,
+}
+
+
 def make_divisible(x, d=8):
     return int(math.ceil(x / d) * d)
 
@@ -93,11 +182,7 @@ def conv_specs(scale="m", nc=1):
 
 def flops_per_image(scale="m", nc=1, size=640):
     """2*MAC over every conv at size x size (78.681 GFLOP for m, nc=1)."""
-    a = arch(scale, nc)
-    # output resolution of each conv, in the order conv_specs() emits them
     total = 0.0
-    res = {}
-    s = size
     strides = {"model.0": 2, "model.1": 4, "model.2": 4, "model.3": 8, "model.4": 8, "model.5": 16,
                "model.6": 16, "model.7": 32, "model.8": 32, "model.9": 32, "model.12": 16,
                "model.15": 8, "model.16": 16, "model.18": 16, "model.19": 32, "model.21": 32}
@@ -112,7 +197,10 @@ def flops_per_image(scale="m", nc=1, size=640):
     return total
 
 
-def synthesize(scale="m", nc=1, seed=0, cls_bias=-5.0):
+DEFAULT_GAIN = 2.2
+
+
+def synthesize(scale="m", nc=1, seed=0, cls_bias=-5.0, gains=None):
     """Seeded weights that keep f16 activations in a healthy range through the whole network.
 
     weight ~ U(-b, b) with b = sqrt(3 * gain / fan_in); gain ~ 1/E[silu(z)^2] keeps the second
@@ -122,16 +210,15 @@ def synthesize(scale="m", nc=1, seed=0, cls_bias=-5.0):
     tensors = OrderedDict()
     for name, cout, cin, k, act in conv_specs(scale, nc):
         fan_in = cin * k * k
-        gain = 2.6 if act else 1.0
+        table = GAINS if gains is None else gains
+        gain = table.get(name, DEFAULT_GAIN)
         b = math.sqrt(3.0 * gain / fan_in)
         w = rng.uniform(-b, b, (cout, cin, k, k)).astype(np.float32)
         if act:
             bias = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
         elif ".cv2." in name:  # DFL logits
-            w *= 2.0
             bias = rng.uniform(0.5, 1.5, cout).astype(np.float32)
         else:  # class logits
-            w *= 3.0
             bias = np.full(cout, cls_bias, np.float32) + rng.uniform(-0.2, 0.2, cout).astype(np.float32)
         tensors[name + ".weight"] = w
         tensors[name + ".bias"] = bias

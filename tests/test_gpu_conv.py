@@ -1,0 +1,96 @@
+"""GPU parity of the MFMA implicit-GEMM conv kernel (one layer at a time, every tile shape)
+against plain PyTorch fp32 conv2d on the CPU.  Inputs and weights are pre-rounded to f16, so the
+only difference is f32 accumulation order: tolerance 2e-3 relative to the output scale."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+
+@pytest.fixture(scope="module")
+def rmr():
+    import rm_radar_amd as r
+    assert r.device_count() >= 1
+    return r
+
+
+def r16(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def ref_conv(x_nhwc, w, b, stride, pad, silu, res):
+    y = F.conv2d(torch.from_numpy(x_nhwc).permute(0, 3, 1, 2), torch.from_numpy(w),
+                 torch.from_numpy(b), stride=stride, padding=pad)
+    if silu:
+        y = y * torch.sigmoid(y)
+    y = y.permute(0, 2, 3, 1).numpy()
+    if res is not None:
+        y = y + res
+    return y
+
+
+def run_case(rmr, n, h, w, cin, cout, k, stride, silu, res, tile=-1, seed=0):
+    rng = np.random.default_rng(seed)
+    x = r16(rng.normal(0, 1, (n, h, w, cin)).astype(np.float32))
+    wt = r16((rng.normal(0, 1, (cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+    b = rng.normal(0, 0.5, cout).astype(np.float32)
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    r = r16(rng.normal(0, 1, (n, ho, wo, cout)).astype(np.float32)) if res else None
+    got = rmr.conv2d(x, wt, b, stride, pad, silu, r, tile=tile)
+    want = ref_conv(x, wt, b, stride, pad, silu, r)
+    err = np.abs(got - want).max()
+    assert err <= 2e-3 * max(1.0, np.abs(want).max()), f"max err {err}"
+
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, silu, residual
+    (1, 32, 32, 3, 48, 3, 2, True, False),     # stem: Cin 3 padded to 8, K = 72 padded to 96
+    (2, 16, 16, 48, 96, 3, 2, True, False),    # model.1: K = 432 (not a multiple of 32)
+    (1, 20, 20, 96, 96, 1, 1, True, False),    # C2f cv1
+    (1, 20, 20, 48, 48, 3, 1, True, True),     # bottleneck with shortcut
+    (3, 10, 10, 192, 96, 1, 1, True, False),
+    (1, 9, 13, 288, 288, 3, 1, True, True),    # odd spatial size, M not a tile multiple
+    (1, 8, 8, 1152, 576, 1, 1, True, False),
+    (1, 12, 12, 192, 256, 3, 1, True, False),  # fused head conv (64 + 192)
+    (1, 12, 12, 64, 64, 1, 1, False, False),   # DFL conv: bias, no activation
+    (1, 12, 12, 192, 12, 1, 1, False, False),  # class conv nc=12 -> padded to 16
+    (1, 12, 12, 192, 1, 1, 1, False, False),   # class conv nc=1
+    (2, 40, 40, 96, 192, 3, 2, True, False),
+    (1, 7, 5, 8, 16, 3, 1, False, False),
+    (1, 5, 5, 16, 32, 5, 1, True, False),      # 5x5 window
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_auto_tile(rmr, case):
+    run_case(rmr, *case)
+
+
+def test_conv_every_tile(rmr):
+    from rm_radar_amd import _lib
+    tiles = [(256, 96), (128, 96), (64, 96), (256, 48), (128, 48), (64, 48), (256, 64), (128, 64),
+             (64, 64), (128, 128), (64, 128), (256, 32), (64, 32), (256, 16), (64, 16)]
+    for t, (bm, bn) in enumerate(tiles):
+        cout = bn * 2
+        run_case(rmr, 1, 19, 23, 48, cout, 3, 1, True, True, tile=t, seed=t)   # M = 437: ragged
+        run_case(rmr, 2, 16, 16, 96, bn, 1, 1, False, False, tile=t, seed=100 + t)
+
+
+def test_conv_matches_c_oracle(rmr, oracle):
+    # the plain-C direct convolution (oracle/rmr_oracle.c) agrees with both
+    rng = np.random.default_rng(5)
+    x = r16(rng.normal(0, 1, (1, 10, 12, 16)).astype(np.float32))
+    wt = r16((rng.normal(0, 1, (32, 16, 3, 3)) / 12).astype(np.float32))
+    b = rng.normal(0, 0.5, 32).astype(np.float32)
+    got = rmr.conv2d(x, wt, b, 1, 1, True)
+    want = oracle.conv2d_nchw(x.transpose(0, 3, 1, 2), wt, b, 1, 1, True).transpose(0, 2, 3, 1)
+    assert np.abs(got - want).max() <= 2e-3
+
+
+def test_conv_bad_arguments(rmr):
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 4, 4, 8), np.float32), np.zeros((48, 8, 3, 3), np.float32), None, 1, 1,
+                   False, tile=0)  # tile 0 has BN = 96, 48 is not a multiple
