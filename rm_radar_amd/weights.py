@@ -35,89 +35,89 @@ SCALES = {  # depth, width, max_channels  (Ultralytics yolov8.yaml)
 # per-layer gains from tools/calibrate_gains.py (scale m): unit post-activation std on
 # uniform-noise input, DFL / class logits std 1.5
 GAINS = {
-    "model.0.conv": 6.4100,
-    "model.1.conv": 2.7809,
-    "model.2.cv1.conv": 2.6302,
-    "model.2.m.0.cv1.conv": 2.1683,
-    "model.2.m.0.cv2.conv": 1.5554,
-    "model.2.m.1.cv1.conv": 1.2707,
-    "model.2.m.1.cv2.conv": 3.4144,
-    "model.2.cv2.conv": 1.2325,
-    "model.3.conv": 2.6666,
-    "model.4.cv1.conv": 2.4678,
-    "model.4.m.0.cv1.conv": 1.7147,
-    "model.4.m.0.cv2.conv": 2.1494,
-    "model.4.m.1.cv1.conv": 0.9212,
-    "model.4.m.1.cv2.conv": 2.9039,
-    "model.4.m.2.cv1.conv": 0.4809,
-    "model.4.m.2.cv2.conv": 2.9984,
-    "model.4.m.3.cv1.conv": 0.3793,
-    "model.4.m.3.cv2.conv": 2.0271,
-    "model.4.cv2.conv": 0.5495,
-    "model.5.conv": 2.2836,
-    "model.6.cv1.conv": 2.4788,
-    "model.6.m.0.cv1.conv": 2.5806,
-    "model.6.m.0.cv2.conv": 2.4972,
-    "model.6.m.1.cv1.conv": 1.2623,
-    "model.6.m.1.cv2.conv": 2.4345,
-    "model.6.m.2.cv1.conv": 0.6771,
-    "model.6.m.2.cv2.conv": 1.4707,
-    "model.6.m.3.cv1.conv": 0.3609,
-    "model.6.m.3.cv2.conv": 2.6934,
-    "model.6.cv2.conv": 0.6092,
-    "model.7.conv": 2.5893,
-    "model.8.cv1.conv": 2.2062,
-    "model.8.m.0.cv1.conv": 2.3131,
-    "model.8.m.0.cv2.conv": 2.2198,
-    "model.8.m.1.cv1.conv": 0.9845,
-    "model.8.m.1.cv2.conv": 2.3081,
-    "model.8.cv2.conv": 1.1839,
-    "model.9.cv1.conv": 1.9736,
-    "model.9.cv2.conv": 0.7673,
-    "model.12.cv1.conv": 2.4986,
-    "model.12.m.0.cv1.conv": 3.4060,
-    "model.12.m.0.cv2.conv": 2.3840,
-    "model.12.m.1.cv1.conv": 1.6709,
-    "model.12.m.1.cv2.conv": 2.6329,
-    "model.12.cv2.conv": 2.1522,
-    "model.15.cv1.conv": 2.0205,
-    "model.15.m.0.cv1.conv": 2.6658,
-    "model.15.m.0.cv2.conv": 2.3408,
-    "model.15.m.1.cv1.conv": 2.5392,
-    "model.15.m.1.cv2.conv": 2.8400,
-    "model.15.cv2.conv": 2.2024,
-    "model.16.conv": 3.1060,
-    "model.18.cv1.conv": 2.2553,
-    "model.18.m.0.cv1.conv": 2.7363,
-    "model.18.m.0.cv2.conv": 2.7115,
-    "model.18.m.1.cv1.conv": 3.0334,
-    "model.18.m.1.cv2.conv": 2.4263,
-    "model.18.cv2.conv": 1.9924,
-    "model.19.conv": 2.1215,
-    "model.21.cv1.conv": 2.3141,
-    "model.21.m.0.cv1.conv": 2.6069,
-    "model.21.m.0.cv2.conv": 2.2370,
-    "model.21.m.1.cv1.conv": 2.4912,
-    "model.21.m.1.cv2.conv": 2.3012,
-    "model.21.cv2.conv": 2.3504,
-    "model.22.cv2.0.0.conv": 2.1290,
-    "model.22.cv2.0.1.conv": 2.4702,
-    "model.22.cv2.0.2": 1.7611,
-    "model.22.cv3.0.0.conv": 2.5598,
-    "model.22.cv3.0.1.conv": 2.8013,
-    "model.22.cv3.0.2": 3.0202,
-    "model.22.cv2.1.0.conv": 2.1334,
-    "model.22.cv2.1.1.conv": 1.8237,
-    "model.22.cv2.1.2": 2.5475,
-    "model.22.cv3.1.0.conv": 3.1193,
-    "model.22.cv3.1.1.conv": 2.3806,
-    "model.22.cv3.1.2": 2.5850,
-    "model.22.cv2.2.0.conv": 2.7514,
-    "model.22.cv2.2.1.conv": 2.3615,
-    "model.22.cv2.2.2": 2.1993,
-    "model.22.cv3.2.0.conv": 2.6506,
-    "model.22.cv3.2.1.conv": 2.2883,
-    "model.22.cv3.2.2": 3.7046,
+    "model.0.conv": 5.1261,
+    "model.1.conv": 2.4990,
+    "model.2.cv1.conv": 2.3675,
+    "model.2.m.0.cv1.conv": 1.3338,
+    "model.2.m.0.cv2.conv": 1.3132,
+    "model.2.m.1.cv1.conv": 0.5729,
+    "model.2.m.1.cv2.conv": 7.6461,
+    "model.2.cv2.conv": 0.8697,
+    "model.3.conv": 2.2601,
+    "model.4.cv1.conv": 1.8350,
+    "model.4.m.0.cv1.conv": 2.2417,
+    "model.4.m.0.cv2.conv": 1.5082,
+    "model.4.m.1.cv1.conv": 0.8218,
+    "model.4.m.1.cv2.conv": 2.1527,
+    "model.4.m.2.cv1.conv": 0.3883,
+    "model.4.m.2.cv2.conv": 1.9630,
+    "model.4.m.3.cv1.conv": 0.4410,
+    "model.4.m.3.cv2.conv": 1.6301,
+    "model.4.cv2.conv": 0.4377,
+    "model.5.conv": 2.2674,
+    "model.6.cv1.conv": 2.0937,
+    "model.6.m.0.cv1.conv": 1.8660,
+    "model.6.m.0.cv2.conv": 1.6527,
+    "model.6.m.1.cv1.conv": 1.1910,
+    "model.6.m.1.cv2.conv": 1.8289,
+    "model.6.m.2.cv1.conv": 0.5989,
+    "model.6.m.2.cv2.conv": 1.1163,
+    "model.6.m.3.cv1.conv": 0.3110,
+    "model.6.m.3.cv2.conv": 2.4019,
+    "model.6.cv2.conv": 0.5499,
+    "model.7.conv": 2.0894,
+    "model.8.cv1.conv": 1.9785,
+    "model.8.m.0.cv1.conv": 2.3682,
+    "model.8.m.0.cv2.conv": 1.5393,
+    "model.8.m.1.cv1.conv": 0.8045,
+    "model.8.m.1.cv2.conv": 1.9544,
+    "model.8.cv2.conv": 1.1495,
+    "model.9.cv1.conv": 2.0009,
+    "model.9.cv2.conv": 1.2752,
+    "model.12.cv1.conv": 1.8071,
+    "model.12.m.0.cv1.conv": 1.9639,
+    "model.12.m.0.cv2.conv": 1.7842,
+    "model.12.m.1.cv1.conv": 1.9643,
+    "model.12.m.1.cv2.conv": 1.7475,
+    "model.12.cv2.conv": 2.2504,
+    "model.15.cv1.conv": 2.0883,
+    "model.15.m.0.cv1.conv": 2.3896,
+    "model.15.m.0.cv2.conv": 1.4702,
+    "model.15.m.1.cv1.conv": 1.4743,
+    "model.15.m.1.cv2.conv": 2.7930,
+    "model.15.cv2.conv": 1.8973,
+    "model.16.conv": 2.5577,
+    "model.18.cv1.conv": 2.3968,
+    "model.18.m.0.cv1.conv": 1.7029,
+    "model.18.m.0.cv2.conv": 1.8357,
+    "model.18.m.1.cv1.conv": 2.4765,
+    "model.18.m.1.cv2.conv": 1.9819,
+    "model.18.cv2.conv": 2.1528,
+    "model.19.conv": 2.2015,
+    "model.21.cv1.conv": 2.1947,
+    "model.21.m.0.cv1.conv": 1.9585,
+    "model.21.m.0.cv2.conv": 1.9546,
+    "model.21.m.1.cv1.conv": 2.3910,
+    "model.21.m.1.cv2.conv": 1.8386,
+    "model.21.cv2.conv": 1.9997,
+    "model.22.cv2.0.0.conv": 1.6220,
+    "model.22.cv2.0.1.conv": 2.3455,
+    "model.22.cv2.0.2": 1.8183,
+    "model.22.cv3.0.0.conv": 2.0360,
+    "model.22.cv3.0.1.conv": 1.8492,
+    "model.22.cv3.0.2": 1.4662,
+    "model.22.cv2.1.0.conv": 2.7710,
+    "model.22.cv2.1.1.conv": 2.6901,
+    "model.22.cv2.1.2": 2.3255,
+    "model.22.cv3.1.0.conv": 2.6705,
+    "model.22.cv3.1.1.conv": 2.6942,
+    "model.22.cv3.1.2": 1.8508,
+    "model.22.cv2.2.0.conv": 2.0483,
+    "model.22.cv2.2.1.conv": 1.3081,
+    "model.22.cv2.2.2": 2.6834,
+    "model.22.cv3.2.0.conv": 2.4459,
+    "model.22.cv3.2.1.conv": 2.0904,
+    "model.22.cv3.2.2": 6.2443,
 }
 
 
@@ -198,6 +198,10 @@ def flops_per_image(scale="m", nc=1, size=640):
 
 
 DEFAULT_GAIN = 2.2
+# wide conv biases: part of every layer's variance then comes from a constant rather than from
+# the (rounding-noise carrying) input, which keeps the random network from amplifying f16
+# rounding differences chaotically -- trained networks are likewise robust to f16
+BIAS_AMP = 1.2
 
 
 def synthesize(scale="m", nc=1, seed=0, cls_bias=-5.0, gains=None):
@@ -215,7 +219,7 @@ def synthesize(scale="m", nc=1, seed=0, cls_bias=-5.0, gains=None):
         b = math.sqrt(3.0 * gain / fan_in)
         w = rng.uniform(-b, b, (cout, cin, k, k)).astype(np.float32)
         if act:
-            bias = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+            bias = rng.uniform(-BIAS_AMP, BIAS_AMP, cout).astype(np.float32)
         elif ".cv2." in name:  # DFL logits
             bias = rng.uniform(0.5, 1.5, cout).astype(np.float32)
         else:  # class logits
