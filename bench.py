@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X: frames/sec of the per-frame
+detect + locate hot path (640x640 BGR frame + 30k-point cloud), synthetic data.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one batch of BATCH frames (default 64, BASELINE configs[2]: "Batch=64 synthetic
+640x640 frames + 30k-pt clouds on one MI355X (throughput mode)") through the whole hot path:
+  locate   per frame, in stream order (the Locator is stateful): update -> cluster -> keep
+  detect   car YOLOv8m over the 64 frames, armor YOLOv8m over 64*CROPS crops, decode+NMS
+  search   per frame: robots located against that frame's kept clusters
+  gather   (N > 1) one RCCL all-gather of the fixed-size robot records
+Inputs are resident in HBM before the timed region.  Weights are seeded synthetic YOLOv8m
+(the reference's car.onnx / armor.onnx are absent); with those the car stage yields arbitrary
+boxes, so CROPS fixed crop rects per frame are injected for the armor stage -- the car stage still
+runs in full (forward + decode + NMS).  Multi-GPU: streams shard across ranks (weak scaling: every
+rank processes its own BATCH frames per step), no data-path collective.
+
+Prints ONE JSON line (rank 0).  Extra keys: p50_ms_batch1 (latency of one frame incl. H2D),
+roofline (dominant kernel = conv_igemm_f16, HIP events on its own stream), cpu_baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--crops", type=int, default=4)   # K: kOptBatchSize, sample_radar.h:34
+    ap.add_argument("--points", type=int, default=30000)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=1)
+    return ap.parse_args()
+
+
+def crop_rects(rng, n_frames, k, size):
+    out = np.zeros((n_frames, k, 4), np.int32)
+    for f in range(n_frames):
+        for i in range(k):
+            w = int(rng.integers(size // 8, size // 3))
+            h = int(rng.integers(size // 8, size // 3))
+            out[f, i] = (int(rng.integers(0, size - w)), int(rng.integers(0, size - h)), w, h)
+    return out
+
+
+def make_inputs(args, rank):
+    """BATCH frames of one camera/LiDAR stream: images + clouds + robot rects (numpy)."""
+    import scenes
+    size = (args.size, args.size)
+    rng = np.random.default_rng(100 + rank)
+    rects = crop_rects(rng, args.batch, args.crops, args.size)
+    images = np.stack([scenes.synthetic_image(rank * 10000 + f, size) for f in range(args.batch)])
+    clouds = np.zeros((args.batch, args.points, 4), np.float32)
+    crng = np.random.default_rng(200 + rank)
+    for f in range(args.batch):
+        robots = [(tuple(float(v) for v in r), float(crng.uniform(1000, 3000)), int(crng.integers(40, 400)))
+                  for r in rects[f]] if f >= 2 else []
+        clouds[f] = scenes.make_cloud(crng, args.points, scenes.K640, scenes.SAMPLE_L2C, size, robots)
+    return images, clouds, rects
+
+
+def cpu_baseline(args, packs, images, clouds, rects):
+    """The same frame on the host CPU: C oracle (pre / decode+NMS / locate) + PyTorch-CPU fp32
+    YOLOv8m (oneDNN) standing in for ONNX-Runtime-CPU + PCL, which this image lacks."""
+    import torch
+
+    import oracle
+    import scenes
+    from oracle import yolov8_ref as R
+    car, armor = R.load(packs[0]), R.load(packs[1])
+    loc = oracle.Locator(args.size, args.size, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+    n = max(1, args.cpu_frames)
+    t0 = time.perf_counter()
+    for f in range(n):
+        img = images[f]
+        loc.update(clouds[f])
+        loc.cluster()
+        blob, p = oracle.preprocess(img)
+        oracle.postprocess(car.forward(blob[None])[0], 1, 0.65, 0.25, p)
+        blobs, pps = zip(*[oracle.preprocess(img, crop=tuple(int(v) for v in r)) for r in rects[f]])
+        outs = armor.forward(np.stack(blobs))
+        for o, pc in zip(outs, pps):
+            oracle.postprocess(o, 12, 0.65, 0.5, pc)
+        for r in rects[f]:
+            loc.search(tuple(float(v) for v in r))
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} frame(s) of the same workload (1 car + {args.crops} armor YOLOv8m forwards in "
+                      f"PyTorch-CPU fp32, C oracle pre/post/locate), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import rm_radar_amd as rmr
+    import scenes
+    from rm_radar_amd import dist as rd
+    from rm_radar_amd import weights as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    pack_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rmr_packs")
+    os.makedirs(pack_dir, exist_ok=True)
+    packs = (os.path.join(pack_dir, f"car_r{rank}.rmrw"), os.path.join(pack_dir, f"armor_r{rank}.rmrw"))
+    W.make_synthetic_pack(packs[0], "m", 1, seed=1, cls_bias=-6.0)
+    W.make_synthetic_pack(packs[1], "m", 12, seed=2, cls_bias=-6.0)
+
+    images, clouds, rects = make_inputs(args, rank)
+    size = (args.size, args.size)
+    d_images = torch.from_numpy(images).to(dev)
+    d_clouds = torch.from_numpy(clouds).to(dev)
+    img_list = [d_images[f] for f in range(args.batch)]
+
+    B, K = args.batch, args.crops
+    rdet = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1),
+                             device=local, max_frames=B)
+    loc = rmr.Locator(args.size, args.size, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32),
+                      device=local, max_frames=B)
+    cap = rdet.max_cars
+    flops_frame = W.flops_per_image("m", 1) + K * W.flops_per_image("m", 12)
+
+    def step():
+        for f in range(B):  # stream order: the Locator carries temporal state
+            loc.update(d_clouds[f])
+            loc.cluster()
+            loc.keep(f)
+        robots, counts = rdet.detect_batch_raw(img_list, rects)
+        import ctypes as C
+        from rm_radar_amd import _lib
+        base = C.addressof(robots)
+        for f in range(B):
+            if counts[f]:
+                ptr = C.cast(base + f * cap * C.sizeof(_lib.Robot), C.POINTER(_lib.Robot))
+                loc.search_raw(ptr, int(counts[f]), frame=f)
+        block = torch.from_numpy(rd.pack_records(robots, counts, cap, rank, cap))
+        if world > 1:
+            block = rd.all_gather_records(block.to(dev))
+        return block, counts
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    with rmr.profile(local) as prof:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            block, counts = step()
+        sync_all()
+        dt = time.perf_counter() - t0
+        stats = prof.read()
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    n_located = int(((block.view(-1, 12)[:, 9] & 2) != 0).sum().item()) if block.numel() else 0
+    result = None
+    if rank == 0:
+        frames = B * args.steps * world
+        conv = stats.get("conv_igemm_f16", {"total_ms": 0.0, "flops": 0.0, "launches": 0})
+        ach = conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0
+        kernels = {k: {"launches": v["launches"], "ms_per_step": round(v["total_ms"] / args.steps, 4)}
+                   for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
+        result = {
+            "metric": "frames/sec detect+locate (640x640 + 30k-pt cloud)",
+            "value": frames / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: batch={B} synthetic {args.size}x{args.size} frames + "
+                                   f"{args.points}-pt clouds per step per GPU, car YOLOv8m + {K} injected "
+                                   f"armor crops/frame (YOLOv8m, nc=12), seeded synthetic weights, f16 MFMA",
+                       "frames_per_step_per_gpu": B, "crops_per_frame": K, "points_per_cloud": args.points,
+                       "streams_per_gpu": 1, "gflop_per_frame": round(flops_frame / 1e9, 3)},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f16", "achieved": round(ach, 2),
+                         "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": conv["launches"] / max(args.steps, 1),
+                         "avg_launch_ms": round(conv["total_ms"] / max(conv["launches"], 1), 5),
+                         "algorithmic_gflop_per_launch": round(conv["flops"] / max(conv["launches"], 1) / 1e9, 4)},
+            "kernels": kernels,
+            "end_to_end_tflops": round(flops_frame * frames / dt / 1e12, 2),
+            "located_last_step": n_located,
+        }
+
+    # ---- batch-1 latency (p50), host inputs: H2D inside the timed region ----
+    if rank == 0 and not args.no_latency:
+        rdet.close()
+        loc.close()
+        r1 = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1), device=local)
+        l1 = rmr.Locator(args.size, args.size, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=local)
+        lat = []
+        for i in range(60):
+            f = i % B
+            t0 = time.perf_counter()
+            l1.update(clouds[f])
+            l1.cluster()
+            rb = r1.detect_batch([images[f]], forced_crops=[rects[f]])[0]
+            l1.search(rb)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat = np.array(lat[10:])
+        result["p50_ms_batch1"] = round(float(np.percentile(lat, 50)), 3)
+        result["p99_ms_batch1"] = round(float(np.percentile(lat, 99)), 3)
+        r1.close()
+        l1.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, packs, images, clouds, rects)
+    if rank == 0:
+        if "cpu_baseline" not in result:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,7 +61,6 @@ Detector::Detector(const rmr_detector_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg
     if (cfg.classes <= 0) fail(RMR_ERR_INVALID_ARGUMENT, "Detector: classes must be positive");
     if (cfg.max_batch_size < 1) fail(RMR_ERR_INVALID_ARGUMENT, "Detector: max_batch_size must be >= 1");
     if (cfg.input_channels != 3) fail(RMR_ERR_INVALID_ARGUMENT, "Detector: only 3-channel BGR input is supported");
-    if (const char* e = std::getenv("RMR_DET_CAP")) det_cap_ = std::max(16, std::atoi(e));
     RMR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     net_ = std::make_unique<Yolov8>(ctx_, cfg.engine_path, cfg.classes, cfg.input_width, cfg.input_height,
                                     cfg.max_batch_size);
@@ -71,8 +70,9 @@ Detector::Detector(const rmr_detector_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg
     descs_pin_.alloc(B);
     pp_pin_.alloc(B);
     post_scratch_.alloc(postprocess_scratch_bytes(B, net_->anchors()));
+    det_cap_ = net_->anchors();  // every anchor can survive, as in the reference (detector.cu:549)
     dets_dev_.alloc((size_t)B * det_cap_);
-    dets_pin_.alloc((size_t)B * det_cap_);
+    dets_pin_.alloc((size_t)B * kHeadRows);
     counts_dev_.alloc(B);
     counts_pin_.alloc(B);
 }
@@ -109,9 +109,13 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
     launch_postprocess(ctx_, stream_, net_->output(), n, net_->channels(), net_->anchors(), net_->nc(),
                        cfg_.nms_thresh, cfg_.conf_thresh, pp_dev_.p, post_scratch_.p, dets_dev_.p,
                        counts_dev_.p, det_cap_);
+    // D2H: the counts plus the first kHeadRows rows of every image in one strided copy (the
+    // reference copies all 8400 rows of every image, detector.cu:549-551); images with more
+    // survivors are topped up after the sync in detect_staged()
     RMR_HIP(hipMemcpyAsync(counts_pin_.p, counts_dev_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    RMR_HIP(hipMemcpyAsync(dets_pin_.p, dets_dev_.p, (size_t)n * det_cap_ * sizeof(rmr_detection),
-                           hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipMemcpy2DAsync(dets_pin_.p, kHeadRows * sizeof(rmr_detection), dets_dev_.p,
+                             (size_t)det_cap_ * sizeof(rmr_detection), kHeadRows * sizeof(rmr_detection), n,
+                             hipMemcpyDeviceToHost, stream_));
 }
 
 void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out) {
@@ -120,12 +124,19 @@ void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std:
     if (n == 0) return;  // Q10d: the reference would abort on an empty batch; return nothing
     enqueue(descs, true);
     RMR_HIP(hipStreamSynchronize(stream_));
+    bool extra = false;
     for (int i = 0; i < n; ++i) {
         const int c = counts_pin_.p[i];
-        if (c > det_cap_)
-            fail(RMR_ERR_CAPACITY, "Detector: image %d produced %d detections (internal cap %d; set RMR_DET_CAP)", i, c, det_cap_);
-        out[i].assign(dets_pin_.p + (size_t)i * det_cap_, dets_pin_.p + (size_t)i * det_cap_ + c);
+        out[i].resize(c);
+        std::copy(dets_pin_.p + (size_t)i * kHeadRows, dets_pin_.p + (size_t)i * kHeadRows + std::min(c, kHeadRows),
+                  out[i].begin());
+        if (c > kHeadRows) {
+            RMR_HIP(hipMemcpyAsync(out[i].data() + kHeadRows, dets_dev_.p + (size_t)i * det_cap_ + kHeadRows,
+                                   (size_t)(c - kHeadRows) * sizeof(rmr_detection), hipMemcpyDeviceToHost, stream_));
+            extra = true;
+        }
     }
+    if (extra) RMR_HIP(hipStreamSynchronize(stream_));
 }
 
 static void fill_descs(const std::vector<FrameStage::Frame>& fr, const int* crops, std::vector<LetterboxDesc>& descs) {

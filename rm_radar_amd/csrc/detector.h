@@ -52,7 +52,8 @@ class Detector {
     hipStream_t stream_ = nullptr;
     std::unique_ptr<Yolov8> net_;
     FrameStage stage_;
-    int det_cap_ = 512;
+    static constexpr int kHeadRows = 64;  // rows per image fetched with the counts
+    int det_cap_ = 0;
     DevBuf<LetterboxDesc> descs_dev_;
     DevBuf<rmr_preparam> pp_dev_;
     DevBuf<uint8_t> post_scratch_;
