@@ -21,6 +21,11 @@
 // same XCD (its 4 MiB L2 then serves the re-reads of that block).
 #include "conv_igemm.h"
 
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
 namespace rmr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -276,7 +281,18 @@ void launch_conv(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a, int tile
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad +
                                 (double)a.Cout_pad * a.K);
-    ProfScope ps(ctx.prof, stream, "conv_igemm_f16", flops, bytes);
+    // RMR_PROFILE_LAYERS=1: one profile entry per GEMM shape instead of one for the kernel
+    static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
+    static std::mutex name_mu;
+    static std::map<std::string, std::string> names;
+    const char* pname = "conv_igemm_f16";
+    if (per_layer && ctx.prof.on) {
+        char buf[48];
+        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d t%d", a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
+        std::lock_guard<std::mutex> lk(name_mu);
+        pname = names.emplace(buf, buf).first->second.c_str();
+    }
+    ProfScope ps(ctx.prof, stream, pname, flops, bytes);
     t.kernel<<<grid, 256, 0, stream>>>(a);
     RMR_HIP(hipGetLastError());
 }
