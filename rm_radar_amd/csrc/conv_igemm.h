@@ -24,6 +24,7 @@ struct ConvArgs {
     int Cout_pad;       // multiple of the tile's BN
     int K, Kp, M;       // K = KH*KW*Cin, Kp = K rounded up to 32, M = N*Ho*Wo
     int act;            // 1 = SiLU
+    const void* zeros;  // >= 16 bytes of zeros in device memory: where padding taps are read from
     double flops;       // algorithmic FLOPs of this launch (true channel counts), for profiling
 };
 
@@ -35,7 +36,7 @@ int conv_num_tiles();
 ConvTile conv_tile(int id);
 // best tile for (M, Cout_pad) on a chip with num_cus compute units
 int conv_pick_tile(int M, int cout_pad, int num_cus);
-void launch_conv(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a, int tile);
+void launch_conv(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
 
 // Packs OIHW f32 weights into the engine's [Cout_pad][Kp] f16 layout (host side).
 // cin_pad >= cin: extra input channels get zero weights.

@@ -30,6 +30,7 @@ namespace rmr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 8;  // padded LDS row, in halves (80 B)
@@ -101,42 +102,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         wrow[i] = (const _Float16*)a.wt + (long)(n0 + (r < BN ? r : 0)) * a.Kp + kc * 8;
     }
 
-    uint4 a_reg[A_IT], b_reg[B_IT];
-    auto load_tiles = [&](int kt) {
-        const long delta = (long)(k_kh * a.W + k_kw) * a.in_cs + k_ci;
-        const bool kok = k_kh < a.KH;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int ih = (a_hw[i] >> 16) + k_kh;
-            const int iw = (int)(short)(a_hw[i] & 0xffff) + k_kw;
-            const bool ok = kok && ((a_ok >> i) & 1u) && (unsigned)ih < (unsigned)a.H &&
-                            (unsigned)iw < (unsigned)a.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *(const uint4*)((const _Float16*)a.in + a_base[i] + delta);
-            a_reg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) b_reg[i] = *(const uint4*)(wrow[i] + (long)kt * BK);
-        // advance the filter-window position to the next K step
-        k_ci += BK;
-        while (k_ci >= a.Cin) {
-            k_ci -= a.Cin;
-            if (++k_kw == a.KW) {
-                k_kw = 0;
-                ++k_kh;
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            *(uint4*)&As[buf][(row0 + i * RPI) * LDK + kc * 8] = a_reg[i];
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int r = row0 + i * RPI;
-            if (r < BN) *(uint4*)&Bs[buf][r * LDK + kc * 8] = b_reg[i];
-        }
-    };
+    // Staging registers for the next K-step.  (Plain macros, not lambdas: with by-reference
+    // captures hipcc demoted these arrays to LDS/scratch and waited for every load at once.)
+    u32x4 a_reg[A_IT], b_reg[B_IT];
+#define RMR_LOAD_TILES(kt)                                                                         \
+    {                                                                                              \
+        const long delta = (long)(k_kh * a.W + k_kw) * a.in_cs + k_ci;                             \
+        const bool kok = k_kh < a.KH;                                                              \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                         \
+            const int ih = (a_hw[i] >> 16) + k_kh;                                                 \
+            const int iw = (int)(short)(a_hw[i] & 0xffff) + k_kw;                                  \
+            const bool ok = kok && ((a_ok >> i) & 1u) && (unsigned)ih < (unsigned)a.H &&           \
+                            (unsigned)iw < (unsigned)a.W;                                          \
+            /* padding taps / K tail / rows past M read a zero page: the load stays              \
+               unconditional so its latency overlaps the MFMAs */                                  \
+            const u32x4* src = ok ? (const u32x4*)((const _Float16*)a.in + a_base[i] + delta)      \
+                                  : (const u32x4*)a.zeros;                                         \
+            a_reg[i] = *src;                                                                       \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                           \
+            b_reg[i] = *(const u32x4*)(wrow[i] + (long)(kt) * BK);                                 \
+        k_ci += BK;                                                                                \
+        while (k_ci >= a.Cin) {                                                                    \
+            k_ci -= a.Cin;                                                                         \
+            if (++k_kw == a.KW) {                                                                  \
+                k_kw = 0;                                                                          \
+                ++k_kh;                                                                            \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#define RMR_STORE_TILES(buf)                                                                       \
+    {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i)                                           \
+            *(u32x4*)&As[buf][(row0 + i * RPI) * LDK + kc * 8] = a_reg[i];                         \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                         \
+            const int r = row0 + i * RPI;                                                          \
+            if (r < BN) *(u32x4*)&Bs[buf][r * LDK + kc * 8] = b_reg[i];                            \
+        }                                                                                          \
+    }
 
     floatx4 acc[MREP][NREP];
 #pragma unroll
@@ -145,15 +148,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int j = 0; j < NREP; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.Kp / BK;
-    load_tiles(0);
-    store_tiles(0);
+    RMR_LOAD_TILES(0);
+    RMR_STORE_TILES(0);
     __syncthreads();
 
     const int frag_row = lane & 15;
     const int frag_k = (lane >> 4) * 8;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
+        if (kt + 1 < nk) RMR_LOAD_TILES(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);  // loads are issued before, and wait after, the MFMAs
 
         half8 xf[MREP], wf[NREP];
 #pragma unroll
@@ -168,9 +172,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             for (int j = 0; j < NREP; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
 
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) RMR_STORE_TILES(buf ^ 1);
         __syncthreads();
     }
+
+#undef RMR_LOAD_TILES
+#undef RMR_STORE_TILES
 
     // ---- epilogue: bias, SiLU, residual, store 4 consecutive channels per lane ----
     const int px = lane & 15;
@@ -270,13 +278,14 @@ int conv_pick_tile(int M, int cout_pad, int num_cus) {
     return best >= 0 ? best : smallest;
 }
 
-void launch_conv(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a, int tile) {
+void launch_conv(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     if (tile < 0 || tile >= kNumTiles) fail(RMR_ERR_INVALID_ARGUMENT, "conv: tile %d out of range", tile);
     const TileDef& t = kTiles[tile];
     if (a.Cout_pad % t.bn) fail(RMR_ERR_LOGIC, "conv: Cout_pad %d not a multiple of tile BN %d", a.Cout_pad, t.bn);
     if (a.Cin % 8 || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 || a.Kp % BK)
         fail(RMR_ERR_LOGIC, "conv: misaligned view (Cin %d in_cs %d in_co %d out_cs %d out_co %d Kp %d)",
              a.Cin, a.in_cs, a.in_co, a.out_cs, a.out_co, a.Kp);
+    a.zeros = ctx.zero_page();
     const int grid = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad +
