@@ -1,5 +1,7 @@
 // api_detect.cpp -- C-ABI entry points (include/rmr.h) for Detector, RobotDetector and the
 // single-layer conv hook.
+#include <cstdlib>
+
 #include "common.h"
 #include "conv_igemm.h"
 #include "detector.h"
@@ -164,14 +166,43 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         a.Cout_pad = cout_pad;
         a.M = (int)npx_out;
         a.act = silu;
-        int t = tile;
-        if (t < 0) t = conv_pick_tile(a.M, cout_pad, ctx.num_cus);
-        if (t >= conv_num_tiles() || cout_pad % conv_tile(t).bn)
-            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: tile %d cannot produce %d channels", t, cout_pad);
-        launch_conv(ctx, ctx.stream, a, t);
+        a.in_bytes = (unsigned)(hx.size() * sizeof(__half));
+        a.wt_bytes = (unsigned)(packed.size() * sizeof(__half));
+        DevBuf<long long> dtiming;
+        const bool want_timing = std::getenv("RMR_CONV_TIMING") != nullptr;
+        if (want_timing) {
+            dtiming.alloc(8);
+            RMR_HIP(hipMemsetAsync(dtiming.p, 0, 64, ctx.stream));
+            a.timing = dtiming.p;
+        }
+        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..: conv_halo tile
+        if (tile < 0) {
+            launch_conv_auto(ctx, ctx.stream, a);
+        } else if (tile >= 200) {
+            const int t = tile - 200;
+            if (t >= conv_halo_num_tiles() || !conv_halo_supported(a, t))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: halo tile %d cannot run this layer", t);
+            launch_conv_halo(ctx, ctx.stream, a, t);
+        } else if (tile >= 100) {
+            const int t = tile - 100;
+            if (t >= conv_dma_num_tiles() || cout_pad % conv_dma_tile(t).bn || !conv_dma_supported(a))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: dma tile %d cannot run this layer", t);
+            launch_conv_dma(ctx, ctx.stream, a, t);
+        } else {
+            if (tile >= conv_num_tiles() || cout_pad % conv_tile(tile).bn)
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: tile %d cannot produce %d channels", tile, cout_pad);
+            launch_conv(ctx, ctx.stream, a, tile);
+        }
         std::vector<float> hy(npx_out * cout_pad);
         RMR_HIP(hipMemcpyAsync(hy.data(), dy.p, hy.size() * sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
         RMR_HIP(hipStreamSynchronize(ctx.stream));
+        if (want_timing) {
+            long long t[8] = {0};
+            RMR_HIP(hipMemcpy(t, dtiming.p, 64, hipMemcpyDeviceToHost));
+            const double n = t[5] ? (double)t[5] : 1.0;
+            fprintf(stderr, "[conv timing] slices %lld | per slice cycles: vmcnt-wait %.0f barrier %.0f issue %.0f ds_read %.0f mfma %.0f\n",
+                    t[5], t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n);
+        }
         for (size_t p = 0; p < npx_out; ++p)
             for (int c = 0; c < cout; ++c) y[p * cout + c] = hy[p * cout_pad + c];
     });

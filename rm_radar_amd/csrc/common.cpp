@@ -70,13 +70,10 @@ DeviceCtx::DeviceCtx(int dev) : device(dev) {
              prop.gcnArchName);
     num_cus = prop.multiProcessorCount;
     RMR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    RMR_HIP(hipMalloc(&zeros_, 256));
-    RMR_HIP(hipMemset(zeros_, 0, 256));
 }
 
 DeviceCtx::~DeviceCtx() {
     if (stream) (void)hipStreamDestroy(stream);
-    if (zeros_) (void)hipFree(zeros_);
 }
 
 int usable_device_count() {

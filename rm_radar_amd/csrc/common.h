@@ -169,8 +169,6 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;  // unit-level entry points run here
     Profiler prof;
     int num_cus = 256;
-    void* zeros_ = nullptr;  // 256 bytes of zeros (conv padding taps read from here)
-    const void* zero_page() const { return zeros_; }
     explicit DeviceCtx(int dev);
     ~DeviceCtx();
     void use() const { RMR_HIP(hipSetDevice(device)); }

@@ -1,0 +1,346 @@
+// conv_halo.hip -- 3x3 / stride 1 / pad 1 convolution with the input staged ONCE per workgroup.
+//
+// conv_igemm / conv_dma gather the im2col matrix, i.e. every input pixel travels L2 -> LDS nine
+// times (once per filter tap).  Measured on MI355X the K loop of those kernels is paced by the
+// per-CU vector-memory path (~20 B/clk/CU for 64-128 B row segments): DMA issue takes 760 of the
+// 1380 cycles a wave spends per K slice at 128x96.  For 3x3 convolutions -- 85 % of YOLOv8m's
+// FLOPs -- the fix is to fetch fewer bytes per MAC:
+//
+//   * outputs are taken in LINEAR pixel order m = (n*H + y)*W + x (stride 1, so input and output
+//     share that index).  A workgroup owns BM consecutive outputs; every tap of every one of them
+//     lies in the linear input range [m0 - W - 1, m0 + BM + W + 1).  That range (BM + 2W + 2
+//     pixels x 32 channels) is DMA'd into LDS once per 32-channel chunk, and tap (kh, kw) is just
+//     a row shift of (kh-1)*W + (kw-1) when the MFMA fragments are read: 9 taps reuse one copy.
+//     Taps that fall outside the image read a neighbouring row's pixel; they are zeroed in
+//     registers from a per-pixel 9-bit validity mask (only border pixels have any).
+//   * the LDS image is written lane-linearly by the DMA, so bank conflicts are handled on the
+//     source side with the chunk permutation c ^ (((row >> 2) & 1) << 1), which is conflict-free
+//     for ds_read_b128 fragment reads at EVERY row shift (exhaustively checked).
+//   * weights still stream per (tap, chunk) slice through a 3-deep DMA ring with counted vmcnt;
+//     the next chunk's input range is fetched in 8 portions alongside taps 0..7 of the current
+//     one, so every slice issues the same number of DMA instructions (constant vmcnt immediates).
+//
+// Staged bytes per K slice at 256 x 192: 16 KiB instead of 28 KiB (im2col), and the A part no
+// longer grows with the tile height.
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "conv_igemm.h"
+
+namespace rmr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BSTAGES = 3;       // weight-slice ring
+constexpr int A_SLOTS = 4;       // input-range DMA instructions per slice (taps 0..7 carry them)
+constexpr int A_MAX_ROWS = A_SLOTS * 8 * 16;  // 512 LDS rows
+
+__device__ __forceinline__ float silu_h(float v) { return v / (1.0f + __expf(-v)); }
+
+__device__ __forceinline__ void dma16h(u32x4 rsrc, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+// chunk permutation key of an LDS row (see header)
+__device__ __forceinline__ int hkey(int row) { return ((row >> 2) & 1) << 1; }
+
+template <int WM, int WN, int MREP, int NREP>
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a, const int a_rows) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * MREP * 16;
+    constexpr int BN = WN * NREP * 16;
+    constexpr int NB = BN / 16;                        // weight DMA instructions per slice
+    constexpr int SLOTS = A_SLOTS + NB;                // DMA instructions per slice (workgroup)
+    constexpr int NI = (SLOTS + NW - 1) / NW;          // per wave
+    constexpr int B_STAGE_BYTES = BN * 64;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert((BSTAGES - 1) * NI <= 63, "vmcnt is 6 bits");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const int a_buf_bytes = a_rows * 64;              // one input-range buffer
+    const int b_base = 2 * a_buf_bytes;               // weight ring behind the two input buffers
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nt_count = a.Cout_pad / BN;
+    const int nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int xcd = blockIdx.x & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int m0 = (lid / nt_count) * BM;
+    const int n0 = (lid % nt_count) * BN;
+    const int W = a.W;
+    const int lo = m0 - W - 1;            // input pixel held by LDS row 0
+    const int npix = a.N * a.H * a.W;     // == M
+
+    const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
+                           sgpr(a.in_bytes), sgpr(0x00020000u)};
+    const u32x4 wt_rsrc = {sgpr((unsigned)(size_t)a.wt), sgpr((unsigned)((size_t)a.wt >> 32) & 0xffffu),
+                           sgpr(a.wt_bytes), sgpr(0x00020000u)};
+    constexpr unsigned OOB = 0xfffffff0u;
+
+    // ---- DMA bookkeeping of this lane -------------------------------------------------------
+    const int lrow = lane >> 2;                       // row inside a 16-row DMA block
+    const int lchunk = (lane & 3) ^ hkey(lrow);       // logical 16-byte chunk this lane fetches
+    const int na = a_rows / 16;                       // input-range DMA instructions per chunk
+    // weight rows of this lane's B slots (slot q = wave + NW*j; q >= A_SLOTS are weights)
+    int w_off[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int q = wave + NW * j;
+        const int row = (q - A_SLOTS) * 16 + lrow;
+        w_off[j] = (q >= A_SLOTS && q < SLOTS) ? ((n0 + row) * a.Kp + lchunk * 8) * 2 : 0;
+    }
+    const int chunks = a.Cin / 32;
+
+    const unsigned scratch = sgpr(lds0 + b_base + BSTAGES * B_STAGE_BYTES);  // idle slots land here
+
+    // Issues the DMA instructions that ride on slice (cc, t): the weights of the slice
+    // BSTAGES - 1 ahead and, for taps 0..7, one eighth of the NEXT chunk's input range.
+    // t % 3 is a compile-time constant at every call site (the kw loop is unrolled).
+    auto issue = [&](int cc, int t) {
+        const int ahead = t + BSTAGES - 1;
+        const int ks_c = ahead >= 9 ? cc + 1 : cc, ks_t = ahead >= 9 ? ahead - 9 : ahead;  // slice being fetched
+        const bool w_live = ks_c < chunks;
+        const int wdelta = (ks_t * a.Cin + ks_c * 32) * 2;
+        const int w_stage = ahead % BSTAGES;                // == (9 * ks_c + ks_t) % 3; constant per kw
+        const bool a_live = t < 8 && cc + 1 < chunks;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int q = wave + NW * j;  // wave-uniform slot
+            if (q < A_SLOTS) {
+                const int ia = t * A_SLOTS + q;     // DMA block within the input range
+                const int p = lo + ia * 16 + lrow;  // input pixel of this lane's row
+                if (a_live && ia < na) {
+                    unsigned off = OOB;
+                    if (p >= 0 && p < npix) off = (unsigned)((p * a.in_cs + a.in_co + (cc + 1) * 32 + lchunk * 8) * 2);
+                    dma16h(in_rsrc, sgpr(lds0 + ((cc + 1) & 1) * a_buf_bytes + ia * 1024), off);
+                } else {
+                    dma16h(in_rsrc, scratch, OOB);
+                }
+            } else if (q < SLOTS) {
+                const unsigned off = w_live ? (unsigned)(w_off[j] + wdelta) : OOB;
+                dma16h(wt_rsrc, sgpr(lds0 + b_base + w_stage * B_STAGE_BYTES + (q - A_SLOTS) * 1024), off);
+            } else {
+                dma16h(wt_rsrc, scratch, OOB);
+            }
+        }
+    };
+
+    floatx4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: the whole input range of chunk 0, weight slices 0 .. BSTAGES-2 ------------
+    for (int ia = wave; ia < na; ia += NW) {
+        const int p = lo + ia * 16 + lrow;
+        unsigned off = OOB;
+        if (p >= 0 && p < npix) off = (unsigned)((p * a.in_cs + a.in_co + lchunk * 8) * 2);
+        dma16h(in_rsrc, sgpr(lds0 + ia * 1024), off);
+    }
+    // weight slices 0 .. BSTAGES-2 (taps 0, 1 of chunk 0)
+#pragma unroll
+    for (int s = 0; s < BSTAGES - 1; ++s) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int q = wave + NW * j;
+            if (q >= A_SLOTS && q < SLOTS)
+                dma16h(wt_rsrc, sgpr(lds0 + b_base + s * B_STAGE_BYTES + (q - A_SLOTS) * 1024),
+                       (unsigned)(w_off[j] + s * a.Cin * 2));
+        }
+    }
+    wait_vm<0>();
+
+    // ---- per-lane fragment bookkeeping ------------------------------------------------------
+    const int frow = lane & 15;
+    const int kg = lane >> 4;
+    int a_row[MREP];         // LDS row of this lane's pixel (centre tap) per fragment
+    unsigned a_mask[MREP];   // valid-tap bits of this lane's pixel per fragment
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int q = (wm * MREP + i) * 16 + frow;  // pixel within the tile
+        a_row[i] = q + W + 1;
+        const int m = m0 + q;
+        unsigned mask = 0;
+        if (m < a.M) {
+            const int x = m % W;
+            const int y = (m / W) % a.H;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)W) mask |= 1u << t;
+            }
+        }
+        a_mask[i] = mask;
+    }
+    const int b_frag = b_base + (wn * NREP * 16 + frow) * 64 + ((kg ^ hkey(frow)) * 16);
+
+    for (int cc = 0; cc < chunks; ++cc) {
+        const int a_buf = (cc & 1) * a_buf_bytes;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int t = kh * 3 + kw;  // t % BSTAGES == kw: the ring slot is a compile-time constant
+            wait_vm<(BSTAGES - 2) * NI>();
+            __builtin_amdgcn_s_barrier();
+            issue(cc, t);
+            const int shift = (kh - 1) * W + (kw - 1);
+            const unsigned char* bp = smem + b_frag + kw * B_STAGE_BYTES;
+            half8 xf[MREP], wf[NREP];
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                const int row = a_row[i] + shift;
+                half8 v = *(const half8*)(smem + a_buf + row * 64 + ((kg ^ hkey(row)) * 16));
+                const bool ok = (a_mask[i] >> t) & 1u;
+                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                xf[i] = ok ? v : z;
+            }
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) wf[j] = *(const half8*)(bp + j * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    wait_vm<0>();
+
+    // ---- epilogue: bias, SiLU, residual, store 4 consecutive channels per lane ----
+    const int px = lane & 15;
+    const int cq = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + (wm * MREP + i) * 16 + px;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+            const int n = n0 + (wn * NREP + j) * 16 + cq;
+            const float4 b = *(const float4*)(a.bias + n);
+            float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu_h(v[r]);
+            }
+            if (a.res) {
+                union {
+                    uint2 u;
+                    _Float16 h[4];
+                } rr;
+                rr.u = *(const uint2*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr.h[r];
+            }
+            if (a.out32) {
+                *(float4*)(a.out32 + (long)m * a.out_cs + a.out_co + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                union {
+                    uint2 u;
+                    _Float16 h[4];
+                } o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.h[r] = (_Float16)v[r];
+                *(uint2*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + n) = o.u;
+            }
+        }
+    }
+}
+
+struct HaloTile {
+    int bm, bn, threads;
+    void (*kernel)(const ConvArgs, int);
+};
+
+#define HTILE(WM, WN, MR, NR) \
+    { WM * MR * 16, WN * NR * 16, WM * WN * 64, conv_halo_kernel<WM, WN, MR, NR> }
+
+const HaloTile kHaloTiles[] = {
+    HTILE(4, 2, 4, 6),  // 0: 256 x 192
+    HTILE(4, 2, 4, 3),  // 1: 256 x 96
+    HTILE(4, 2, 4, 9),  // 2: 256 x 288
+    HTILE(4, 2, 4, 4),  // 3: 256 x 128
+    HTILE(4, 2, 4, 8),  // 4: 256 x 256
+    HTILE(4, 2, 4, 2),  // 5: 256 x 64
+    HTILE(4, 2, 2, 6),  // 6: 128 x 192
+    HTILE(4, 2, 2, 9),  // 7: 128 x 288
+    HTILE(2, 2, 4, 3),  // 8: 128 x 96 (4 waves)
+    HTILE(2, 2, 4, 4),  // 9: 128 x 128 (4 waves)
+    HTILE(4, 1, 4, 6),  // 10: 256 x 96 (4 waves)
+};
+constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
+
+int halo_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
+int halo_lds_bytes(const HaloTile& t, int W) {
+    return 2 * halo_rows(t.bm, W) * 64 + BSTAGES * t.bn * 64 + 1024;  // + one scratch KiB for idle slots
+}
+
+}  // namespace
+
+int conv_halo_num_tiles() { return kNumHaloTiles; }
+ConvTile conv_halo_tile(int id) { return ConvTile{kHaloTiles[id].bm, kHaloTiles[id].bn, 32}; }
+
+bool conv_halo_supported(const ConvArgs& a, int tile) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 32) return false;
+    if (a.Ho != a.H || a.Wo != a.W) return false;
+    if (tile < 0) return true;
+    const HaloTile& t = kHaloTiles[tile];
+    return a.Cout_pad % t.bn == 0 && halo_rows(t.bm, a.W) <= A_MAX_ROWS && halo_lds_bytes(t, a.W) <= 160 * 1024;
+}
+
+void launch_conv_halo(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
+    if (tile < 0 || tile >= kNumHaloTiles) fail(RMR_ERR_INVALID_ARGUMENT, "conv_halo: tile %d out of range", tile);
+    if (!conv_halo_supported(a, tile)) fail(RMR_ERR_LOGIC, "conv_halo: layer not supported by tile %d", tile);
+    const HaloTile& t = kHaloTiles[tile];
+    if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4) fail(RMR_ERR_LOGIC, "conv_halo: misaligned view");
+    if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull || a.wt_bytes == 0)
+        fail(RMR_ERR_LOGIC, "conv_halo: buffer sizes not set or input view larger than 3.75 GiB");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const HaloTile& d : kHaloTiles)
+            (void)hipFuncSetAttribute((const void*)d.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    const int rows = halo_rows(t.bm, a.W);
+    const int lds = halo_lds_bytes(t, a.W);
+    const int grid = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
+    const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
+    static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
+    static std::mutex name_mu;
+    static std::map<std::string, std::string> names;
+    const char* pname = "conv_igemm_f16";
+    if (per_layer && ctx.prof.on) {
+        char buf[48];
+        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d h%d", a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
+        std::lock_guard<std::mutex> lk(name_mu);
+        pname = names.emplace(buf, buf).first->second.c_str();
+    }
+    ProfScope ps(ctx.prof, stream, pname, flops, bytes);
+    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows);
+    RMR_HIP(hipGetLastError());
+}
+
+}  // namespace rmr

@@ -22,14 +22,16 @@ struct ConvArgs {
     const __half* res;  // optional residual view, added after the activation
     int res_cs, res_co;
     int Cout_pad;       // multiple of the tile's BN
-    int K, Kp, M;       // K = KH*KW*Cin, Kp = K rounded up to 32, M = N*Ho*Wo
+    int K, Kp, M;       // K = KH*KW*Cin, Kp = K rounded up to 64, M = N*Ho*Wo
     int act;            // 1 = SiLU
-    const void* zeros;  // >= 16 bytes of zeros in device memory: where padding taps are read from
+    unsigned in_bytes;  // bytes addressable from `in` (buffer-load bounds: reads past it return 0)
+    unsigned wt_bytes;  // bytes of the packed weights
+    long long* timing;  // debug: per-phase cycle totals of one wave (RMR_CONV_TIMING), else null
     double flops;       // algorithmic FLOPs of this launch (true channel counts), for profiling
 };
 
 struct ConvTile {
-    int bm, bn;
+    int bm, bn, bk;
 };
 
 int conv_num_tiles();
@@ -37,6 +39,21 @@ ConvTile conv_tile(int id);
 // best tile for (M, Cout_pad) on a chip with num_cus compute units
 int conv_pick_tile(int M, int cout_pad, int num_cus);
 void launch_conv(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+
+// LDS-DMA pipelined variant (conv_dma.hip) for layers with Cin % 32 == 0
+bool conv_dma_supported(const ConvArgs& a);
+int conv_dma_num_tiles();
+ConvTile conv_dma_tile(int id);
+int conv_dma_pick_tile(int M, int cout_pad, int num_cus);
+void launch_conv_dma(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+// halo-staged 3x3 / stride-1 variant (conv_halo.hip): the input range is fetched once per 32-channel
+// chunk and reused by all nine taps
+int conv_halo_num_tiles();
+ConvTile conv_halo_tile(int id);
+bool conv_halo_supported(const ConvArgs& a, int tile);  // tile < 0: any
+void launch_conv_halo(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+// picks the kernel family and tile for a layer (RMR_CONV=igemm|dma overrides) and launches it
+void launch_conv_auto(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a);
 
 // Packs OIHW f32 weights into the engine's [Cout_pad][Kp] f16 layout (host side).
 // cin_pad >= cin: extra input channels get zero weights.

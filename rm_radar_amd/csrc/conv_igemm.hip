@@ -32,20 +32,24 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 8;  // padded LDS row, in halves (80 B)
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
-template <int WM, int WN, int MREP, int NREP>
+template <int WM, int WN, int MREP, int NREP, int BK, bool UT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = WM * MREP * 16;
     constexpr int BN = WN * NREP * 16;
-    constexpr int RPI = 64;  // rows staged per pass: 256 threads / 4 chunks per row
+    // LDS row stride BK+16 halves: with 6 (BK=32) / 10 (BK=64) 16-byte slots per row the four
+    // 16-lane groups of a ds_read_b128 (rows r, k-group g -> slot (r*S+g) mod 16) hit 16
+    // distinct slots: conflict-free fragment reads (BK+8 was 2-way: SQ_LDS_BANK_CONFLICT = 50 %).
+    constexpr int LDK = BK + 16;
+    constexpr int CPR = BK / 8;     // 16-byte chunks per row of the K slice
+    constexpr int RPI = 256 / CPR;  // rows staged per pass of the 256 threads
     constexpr int A_IT = BM / RPI;
     constexpr int B_IT = (BN + RPI - 1) / RPI;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(BM % RPI == 0, "BM must be a multiple of 64");
+    static_assert(BM % RPI == 0, "BM must be a multiple of the staging pass");
+    static_assert(BK == 32 || BK == 64, "BK is 32 or 64");
 
     __shared__ __attribute__((aligned(16))) _Float16 As[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BN * LDK];
@@ -65,12 +69,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int m0 = (lid / nt_count) * BM;
     const int n0 = (lid % nt_count) * BN;
 
+    // Both operands are fetched with buffer loads: 32-bit byte offsets, and an offset past
+    // num_records returns zeros -- that is how padding taps, the K tail and rows past M are
+    // zero-filled without a branch or a select on the data.
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+
     // ---- per-thread im2col bookkeeping (rows are fixed across the K loop) ----
-    const int kc = tid & 3;     // 16-byte chunk within the 32-wide K slice
-    const int row0 = tid >> 2;  // 0..63
-    long a_base[A_IT];
-    int a_hw[A_IT];     // (ih0 << 16) | (iw0 & 0xffff)
-    unsigned a_ok = 0;  // bit i: row i is a real output pixel
+    const int kc = tid % CPR;  // 16-byte chunk within the BK-wide K slice
+    const int row0 = tid / CPR;
+    int a_off[A_IT];        // byte offset of element (n, ih0, iw0, in_co + kc*8); may be "negative"
+    unsigned a_mask[A_IT];  // bit (kh*KW + kw): that filter tap reads a real input pixel
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + row0 + i * RPI;
@@ -82,46 +92,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int n = t / a.Ho;
         const int ih0 = oh * a.stride - a.pad;
         const int iw0 = ow * a.stride - a.pad;
-        a_base[i] = ((long)(n * a.H + ih0) * a.W + iw0) * a.in_cs + a.in_co;
-        a_hw[i] = ih0 * 65536 + (iw0 & 0xffff);
-        a_ok |= (ok ? 1u : 0u) << i;
+        a_off[i] = (((n * a.H + ih0) * a.W + iw0) * a.in_cs + a.in_co + (UT ? kc * 8 : 0)) * 2;
+        unsigned mask = 0;
+        if (ok) {
+            for (int r = 0; r < a.KH; ++r)
+                for (int c = 0; c < a.KW; ++c)
+                    if ((unsigned)(ih0 + r) < (unsigned)a.H && (unsigned)(iw0 + c) < (unsigned)a.W)
+                        mask |= 1u << (r * a.KW + c);
+        }
+        a_mask[i] = mask;
     }
-    // position of this thread's chunk inside the filter window, advanced by BK per step
+    // Position of the K slice inside the filter window.  UT (Cin % BK == 0): a slice never
+    // straddles two taps, so (kh, kw, ci) is wave-uniform and lives in scalar registers;
+    // otherwise every thread tracks the tap of its own 16-byte chunk.
     int k_ci, k_kw, k_kh;
     {
-        const int k = kc * 8;
+        const int k = UT ? 0 : kc * 8;
         k_ci = k % a.Cin;
         const int t = k / a.Cin;
         k_kw = t % a.KW;
         k_kh = t / a.KW;
     }
-    const _Float16* wrow[B_IT];
+    int w_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int r = row0 + i * RPI;
-        wrow[i] = (const _Float16*)a.wt + (long)(n0 + (r < BN ? r : 0)) * a.Kp + kc * 8;
+        w_off[i] = ((n0 + (r < BN ? r : 0)) * a.Kp + kc * 8) * 2;
     }
 
-    // Staging registers for the next K-step.  (Plain macros, not lambdas: with by-reference
-    // captures hipcc demoted these arrays to LDS/scratch and waited for every load at once.)
     u32x4 a_reg[A_IT], b_reg[B_IT];
 #define RMR_LOAD_TILES(kt)                                                                         \
     {                                                                                              \
-        const long delta = (long)(k_kh * a.W + k_kw) * a.in_cs + k_ci;                             \
-        const bool kok = k_kh < a.KH;                                                              \
+        const int delta = ((k_kh * a.W + k_kw) * a.in_cs + k_ci) * 2;                              \
+        const unsigned tap_bit = k_kh < a.KH ? 1u << (k_kh * a.KW + k_kw) : 0u;                     \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                         \
-            const int ih = (a_hw[i] >> 16) + k_kh;                                                 \
-            const int iw = (int)(short)(a_hw[i] & 0xffff) + k_kw;                                  \
-            const bool ok = kok && ((a_ok >> i) & 1u) && (unsigned)ih < (unsigned)a.H &&           \
-                            (unsigned)iw < (unsigned)a.W;                                          \
-            /* padding taps / K tail / rows past M read a zero page: the load stays              \
-               unconditional so its latency overlaps the MFMAs */                                  \
-            const u32x4* src = ok ? (const u32x4*)((const _Float16*)a.in + a_base[i] + delta)      \
-                                  : (const u32x4*)a.zeros;                                         \
-            a_reg[i] = *src;                                                                       \
+            const unsigned off = (a_mask[i] & tap_bit) ? (unsigned)(a_off[i] + delta) : OOB;       \
+            a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);                  \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                           \
-            b_reg[i] = *(const u32x4*)(wrow[i] + (long)(kt) * BK);                                 \
+            b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, w_off[i], (kt) * BK * 2, 0); \
         k_ci += BK;                                                                                \
         while (k_ci >= a.Cin) {                                                                    \
             k_ci -= a.Cin;                                                                         \
@@ -159,24 +168,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         if (kt + 1 < nk) RMR_LOAD_TILES(kt + 1);
         __builtin_amdgcn_sched_barrier(0);  // loads are issued before, and wait after, the MFMAs
 
-        half8 xf[MREP], wf[NREP];
 #pragma unroll
-        for (int i = 0; i < MREP; ++i)
-            xf[i] = *(const half8*)&As[buf][((wm * MREP + i) * 16 + frag_row) * LDK + frag_k];
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            half8 xf[MREP], wf[NREP];
 #pragma unroll
-        for (int j = 0; j < NREP; ++j)
-            wf[j] = *(const half8*)&Bs[buf][((wn * NREP + j) * 16 + frag_row) * LDK + frag_k];
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
+            for (int i = 0; i < MREP; ++i)
+                xf[i] = *(const half8*)&As[buf][((wm * MREP + i) * 16 + frag_row) * LDK + ks * 32 + frag_k];
 #pragma unroll
             for (int j = 0; j < NREP; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                wf[j] = *(const half8*)&Bs[buf][((wn * NREP + j) * 16 + frag_row) * LDK + ks * 32 + frag_k];
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
 
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) RMR_STORE_TILES(buf ^ 1);
         __syncthreads();
     }
-
 #undef RMR_LOAD_TILES
 #undef RMR_STORE_TILES
 
@@ -224,12 +235,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 // ---- tile table ------------------------------------------------------------------------------
 
 struct TileDef {
-    int bm, bn;
-    void (*kernel)(const ConvArgs);
+    int bm, bn, bk;
+    void (*kernel)(const ConvArgs);     // any Cin
+    void (*kernel_ut)(const ConvArgs);  // Cin % BK == 0: wave-uniform filter tap per K slice
 };
 
 #define TILE(WM, WN, MR, NR) \
-    { WM * MR * 16, WN * NR * 16, conv_igemm_kernel<WM, WN, MR, NR> }
+    { WM * MR * 16, WN * NR * 16, 32, conv_igemm_kernel<WM, WN, MR, NR, 32, false>, conv_igemm_kernel<WM, WN, MR, NR, 32, true> }
+#define TILE64(WM, WN, MR, NR) \
+    { WM * MR * 16, WN * NR * 16, 64, conv_igemm_kernel<WM, WN, MR, NR, 64, false>, conv_igemm_kernel<WM, WN, MR, NR, 64, true> }
 
 static const TileDef kTiles[] = {
     TILE(4, 1, 4, 6),  // 0: 256 x 96
@@ -247,13 +261,30 @@ static const TileDef kTiles[] = {
     TILE(4, 1, 1, 2),  // 12:  64 x 32
     TILE(4, 1, 4, 1),  // 13: 256 x 16
     TILE(4, 1, 1, 1),  // 14:  64 x 16
+    // BK = 64: half the barriers and staging bookkeeping per MFMA
+    TILE64(2, 2, 4, 3),  // 15: 128 x 96
+    TILE64(2, 2, 4, 4),  // 16: 128 x 128
+    TILE64(2, 2, 4, 2),  // 17: 128 x 64
+    TILE64(4, 1, 2, 3),  // 18: 128 x 48
+    TILE64(4, 1, 4, 3),  // 19: 256 x 48
+    TILE64(2, 2, 2, 3),  // 20:  64 x 96
+    TILE64(2, 2, 2, 4),  // 21:  64 x 128
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 int conv_num_tiles() { return kNumTiles; }
-ConvTile conv_tile(int id) { return ConvTile{kTiles[id].bm, kTiles[id].bn}; }
+ConvTile conv_tile(int id) { return ConvTile{kTiles[id].bm, kTiles[id].bn, kTiles[id].bk}; }
 
 int conv_pick_tile(int M, int cout_pad, int num_cus) {
+    // RMR_BK=32|64 restricts the choice (tuning experiments); default: BK = 64 where a tile exists
+    static const int want_bk = [] {
+        const char* e = std::getenv("RMR_BK");
+        return e ? std::atoi(e) : 0;
+    }();
+    static const int want_bm = [] {
+        const char* e = std::getenv("RMR_BM");
+        return e ? std::atoi(e) : 0;
+    }();
     // widest BN that divides Cout_pad (fewer re-reads of the activation tile) ...
     int bn = 16;
     for (int cand : {128, 96, 64, 48, 32, 16})
@@ -261,19 +292,25 @@ int conv_pick_tile(int M, int cout_pad, int num_cus) {
             bn = cand;
             break;
         }
-    // ... then the tallest BM that still yields >= 2 workgroups per CU; else the shortest
-    int best = -1, best_bm = 0, smallest = -1, smallest_bm = 1 << 30;
+    // ... then the tallest BM that still yields >= 2 workgroups per CU; else the shortest.
+    // Between equal shapes the deeper K slice wins.
+    int best = -1, smallest = -1;
+    auto better = [&](int t, int cur, bool want_tall) {
+        if (cur < 0) return true;
+        if (kTiles[t].bm != kTiles[cur].bm) return want_tall ? kTiles[t].bm > kTiles[cur].bm : kTiles[t].bm < kTiles[cur].bm;
+        return kTiles[t].bk > kTiles[cur].bk;
+    };
     for (int t = 0; t < kNumTiles; ++t) {
         if (kTiles[t].bn != bn) continue;
+        if (want_bk && kTiles[t].bk != want_bk) continue;
+        if (want_bm && kTiles[t].bm != want_bm) continue;
         const long blocks = (long)((M + kTiles[t].bm - 1) / kTiles[t].bm) * (cout_pad / bn);
-        if (blocks >= 2L * num_cus && kTiles[t].bm > best_bm) {
-            best = t;
-            best_bm = kTiles[t].bm;
-        }
-        if (kTiles[t].bm < smallest_bm) {
-            smallest = t;
-            smallest_bm = kTiles[t].bm;
-        }
+        if (blocks >= 2L * num_cus && better(t, best, true)) best = t;
+        if (better(t, smallest, false)) smallest = t;
+    }
+    if (best < 0 && smallest < 0 && want_bk) {  // no tile of that BK for this BN: lift the restriction
+        for (int t = 0; t < kNumTiles; ++t)
+            if (kTiles[t].bn == bn && better(t, smallest, false)) smallest = t;
     }
     return best >= 0 ? best : smallest;
 }
@@ -282,10 +319,11 @@ void launch_conv(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     if (tile < 0 || tile >= kNumTiles) fail(RMR_ERR_INVALID_ARGUMENT, "conv: tile %d out of range", tile);
     const TileDef& t = kTiles[tile];
     if (a.Cout_pad % t.bn) fail(RMR_ERR_LOGIC, "conv: Cout_pad %d not a multiple of tile BN %d", a.Cout_pad, t.bn);
-    if (a.Cin % 8 || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 || a.Kp % BK)
+    if (a.Cin % 8 || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 || a.Kp % t.bk || a.KH * a.KW > 32)
         fail(RMR_ERR_LOGIC, "conv: misaligned view (Cin %d in_cs %d in_co %d out_cs %d out_co %d Kp %d)",
              a.Cin, a.in_cs, a.in_co, a.out_cs, a.out_co, a.Kp);
-    a.zeros = ctx.zero_page();
+    if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull || a.wt_bytes == 0)
+        fail(RMR_ERR_LOGIC, "conv: buffer sizes not set or input view larger than 3.75 GiB");
     const int grid = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad +
@@ -302,14 +340,27 @@ void launch_conv(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
         pname = names.emplace(buf, buf).first->second.c_str();
     }
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
-    t.kernel<<<grid, 256, 0, stream>>>(a);
+    (a.Cin % t.bk == 0 ? t.kernel_ut : t.kernel)<<<grid, 256, 0, stream>>>(a);
     RMR_HIP(hipGetLastError());
+}
+
+void launch_conv_auto(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a) {
+    static const int mode = [] {
+        const char* e = std::getenv("RMR_CONV");
+        if (!e) return 0;
+        return std::string(e) == "igemm" ? 1 : 2;
+    }();
+    const bool dma = mode != 1 && conv_dma_supported(a);
+    if (dma)
+        launch_conv_dma(ctx, stream, a, conv_dma_pick_tile(a.M, a.Cout_pad, ctx.num_cus));
+    else
+        launch_conv(ctx, stream, a, conv_pick_tile(a.M, a.Cout_pad, ctx.num_cus));
 }
 
 void pack_conv_weights(const float* w, int cout, int cin, int kh, int kw, int cin_pad, int cout_pad,
                        std::vector<__half>& out, int& K, int& Kp) {
     K = kh * kw * cin_pad;
-    Kp = (K + BK - 1) / BK * BK;
+    Kp = (K + 63) / 64 * 64;  // every tile's BK (32 or 64) divides it
     out.assign((size_t)cout_pad * Kp, __float2half(0.f));
     for (int o = 0; o < cout; ++o)
         for (int c = 0; c < cin; ++c)

@@ -78,7 +78,8 @@ class Yolov8 {
               bool out_f32 = false, bool in_is_input = false);
     View c2f(const WeightPack& p, const std::string& name, const View& x, int n, bool shortcut,
              const View* out_view);
-    void run_op(hipStream_t s, const Op& op, int chunk_n, size_t img_base);
+    void run_op(hipStream_t s, int op_index, int chunk_n, size_t img_base);
+    int tune_conv(hipStream_t s, const ConvArgs& a);
 
     DeviceCtx& ctx_;
     int nc_, in_w_, in_h_, max_batch_, chunk_;
@@ -91,6 +92,9 @@ class Yolov8 {
     DevBuf<float> arena32_;
     DevBuf<__half> input_;
     DevBuf<float> output_;
+    // autotuned kernel choice per (op, images in the launch): >= 100 = conv_dma tile id + 100
+    std::map<std::pair<int, int>, int> tuned_;
+    bool autotune_ = true;
 };
 
 }  // namespace rmr

@@ -201,8 +201,9 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
         fail(RMR_ERR_INVALID_ARGUMENT, "weight pack '%s' has %d classes, Detector was given %d", pack_path.c_str(), nc_, expect_nc);
     if (p.reg_max != 16) fail(RMR_ERR_RUNTIME, "only reg_max = 16 is supported");
 
-    int chunk = 32;
+    int chunk = 64;
     if (const char* e = std::getenv("RMR_CHUNK")) chunk = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("RMR_AUTOTUNE")) autotune_ = std::atoi(e) != 0;
     chunk_ = std::min(chunk, max_batch);
 
     int ch[5];
@@ -314,7 +315,57 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
 
 // ---- executor ---------------------------------------------------------------------------------------
 
-void Yolov8::run_op(hipStream_t s, const Op& op, int n, size_t img0) {
+// Times every kernel variant that can run this layer (conv_igemm tiles of both K depths, conv_dma
+// tiles) on the live buffers and returns the fastest.  A conv launch is idempotent (its output
+// slice never aliases its input or residual slice), so re-running it is harmless.  Runs once per
+// (layer, batch) -- the analogue of the reference's TensorRT engine build (detector.cpp:177-243).
+int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
+    std::vector<int> cands;
+    for (int t = 0; t < conv_num_tiles(); ++t)
+        if (a.Cout_pad % conv_tile(t).bn == 0) cands.push_back(t);
+    if (conv_dma_supported(a))
+        for (int t = 0; t < conv_dma_num_tiles(); ++t)
+            if (a.Cout_pad % conv_dma_tile(t).bn == 0) cands.push_back(100 + t);
+    if (conv_halo_supported(a, -1))
+        for (int t = 0; t < conv_halo_num_tiles(); ++t)
+            if (conv_halo_supported(a, t)) cands.push_back(200 + t);
+    hipEvent_t e0, e1;
+    RMR_HIP(hipEventCreate(&e0));
+    RMR_HIP(hipEventCreate(&e1));
+    const bool prof_was_on = ctx_.prof.on;
+    ctx_.prof.on = false;
+    int best = cands.front();
+    float best_ms = 1e30f;
+    for (int c : cands) {
+        // skip tiles that would leave most of the chip idle or are hopelessly oversized
+        const ConvTile t = c >= 200 ? conv_halo_tile(c - 200) : c >= 100 ? conv_dma_tile(c - 100) : conv_tile(c);
+        const long blocks = (long)((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+        if (t.bm >= 256 && blocks < ctx_.num_cus / 2 && a.M > 64) continue;
+        float ms_min = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            RMR_HIP(hipEventRecord(e0, s));
+            if (c >= 200)
+                launch_conv_halo(ctx_, s, a, c - 200);
+            else if (c >= 100)
+                launch_conv_dma(ctx_, s, a, c - 100);
+            else
+                launch_conv(ctx_, s, a, c);
+            RMR_HIP(hipEventRecord(e1, s));
+            RMR_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            RMR_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < ms_min) ms_min = ms;
+        }
+        if (ms_min < best_ms) best_ms = ms_min, best = c;
+    }
+    ctx_.prof.on = prof_was_on;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return best;
+}
+
+void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
+    const Op& op = ops_[op_index];
     auto hptr = [&](const View& v) { return arena_.p + v.off * chunk_; };
     auto fptr = [&](const View& v) { return arena32_.p + v.off * chunk_; };
     switch (op.kind) {
@@ -351,8 +402,22 @@ void Yolov8::run_op(hipStream_t s, const Op& op, int n, size_t img0) {
             a.Kp = cw.Kp;
             a.M = n * a.Ho * a.Wo;
             a.act = op.act;
+            a.in_bytes = (unsigned)((size_t)n * a.H * a.W * a.in_cs * sizeof(__half));
+            a.wt_bytes = (unsigned)((size_t)cw.cout_pad * cw.Kp * sizeof(__half));
             a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
-            launch_conv(ctx_, s, a, conv_pick_tile(a.M, a.Cout_pad, ctx_.num_cus));
+            if (!autotune_) {
+                launch_conv_auto(ctx_, s, a);
+                break;
+            }
+            auto key = std::make_pair(op_index, n);
+            auto it = tuned_.find(key);
+            if (it == tuned_.end()) it = tuned_.emplace(key, tune_conv(s, a)).first;
+            if (it->second >= 200)
+                launch_conv_halo(ctx_, s, a, it->second - 200);
+            else if (it->second >= 100)
+                launch_conv_dma(ctx_, s, a, it->second - 100);
+            else
+                launch_conv(ctx_, s, a, it->second);
             break;
         }
         case OP_SPPF:
@@ -374,7 +439,7 @@ void Yolov8::forward(hipStream_t s, int batch) {
     if (batch < 0 || batch > max_batch_) fail(RMR_ERR_CAPACITY, "forward: batch %d exceeds max_batch_size %d", batch, max_batch_);
     for (int c0 = 0; c0 < batch; c0 += chunk_) {
         const int n = std::min(chunk_, batch - c0);
-        for (const Op& op : ops_) run_op(s, op, n, (size_t)c0);
+        for (int i = 0; i < (int)ops_.size(); ++i) run_op(s, i, n, (size_t)c0);
     }
 }
 

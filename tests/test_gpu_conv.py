@@ -72,11 +72,52 @@ def test_conv_auto_tile(rmr, case):
 def test_conv_every_tile(rmr):
     from rm_radar_amd import _lib
     tiles = [(256, 96), (128, 96), (64, 96), (256, 48), (128, 48), (64, 48), (256, 64), (128, 64),
-             (64, 64), (128, 128), (64, 128), (256, 32), (64, 32), (256, 16), (64, 16)]
+             (64, 64), (128, 128), (64, 128), (256, 32), (64, 32), (256, 16), (64, 16),
+             (128, 96), (128, 128), (128, 64), (128, 48), (256, 48), (64, 96), (64, 128)]  # 15.. : BK = 64
     for t, (bm, bn) in enumerate(tiles):
         cout = bn * 2
         run_case(rmr, 1, 19, 23, 48, cout, 3, 1, True, True, tile=t, seed=t)   # M = 437: ragged
         run_case(rmr, 2, 16, 16, 96, bn, 1, 1, False, False, tile=t, seed=100 + t)
+
+
+def test_conv_dma_every_tile(rmr):
+    # the LDS-DMA pipelined kernel (conv_dma.hip): tile ids 100.., needs Cin % 32 == 0
+    tiles = [(128, 96), (256, 96), (64, 96), (128, 128), (64, 128), (128, 64), (64, 64), (256, 48),
+             (128, 48), (64, 48), (256, 16), (64, 16), (256, 32), (64, 32),
+             (256, 192), (256, 96), (512, 96), (256, 128), (256, 256), (256, 288), (128, 288), (128, 192),  # 8 waves
+             (128, 96), (256, 96), (64, 96), (128, 128), (64, 128), (128, 64), (256, 48), (256, 192),
+             (256, 96), (256, 128), (128, 288), (128, 192)]  # BK = 64
+    for t, (bm, bn) in enumerate(tiles):
+        run_case(rmr, 1, 19, 23, 64, bn * 2, 3, 1, True, True, tile=100 + t, seed=t)    # ragged M, padding taps
+        run_case(rmr, 2, 16, 16, 96, bn, 1, 1, False, False, tile=100 + t, seed=50 + t)  # 1x1, 3 K slices
+        run_case(rmr, 1, 20, 20, 32, bn, 3, 2, True, False, tile=100 + t, seed=90 + t)   # stride 2
+    run_case(rmr, 3, 40, 40, 192, 192, 3, 1, True, True, tile=100, seed=7)              # 54 K slices, 38 blocks
+    run_case(rmr, 1, 9, 9, 64, 96, 5, 1, True, False, tile=102, seed=8)                 # 5x5 window
+    run_case(rmr, 2, 20, 20, 96, 96, 3, 1, True, True, tile=122, seed=9)                # BK 64, Cin 96: slices straddle taps
+    run_case(rmr, 1, 20, 20, 288, 288, 3, 1, True, True, tile=132, seed=10)             # K = 2592 = 40.5 slices of 64
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 4, 4, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
+                   False, tile=100)  # Cin = 48 is not a multiple of 32
+
+
+def test_conv_halo_every_tile(rmr):
+    # halo-staged 3x3 / stride-1 kernel (conv_halo.hip): tile ids 200..; input range staged once,
+    # taps are row shifts, image borders (and image-to-image boundaries inside a tile) are masked
+    tiles = [(256, 192), (256, 96), (256, 288), (256, 128), (256, 256), (256, 64), (128, 192), (128, 288),
+             (128, 96), (128, 128), (256, 96)]
+    for t, (bm, bn) in enumerate(tiles):
+        run_case(rmr, 3, 20, 20, 64, bn, 3, 1, True, True, tile=200 + t, seed=t)          # 3 images per ~5 tiles
+        run_case(rmr, 1, 19, 23, 32, bn * 2, 3, 1, True, False, tile=200 + t, seed=40 + t)  # odd W, ragged M
+    run_case(rmr, 2, 40, 40, 192, 192, 3, 1, True, True, tile=200, seed=70)   # 6 chunks, 54 slices
+    run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, True, tile=201, seed=71)     # W = 80: 418-row input range
+    run_case(rmr, 2, 20, 20, 288, 288, 3, 1, True, True, tile=207, seed=72)   # 9 chunks
+    run_case(rmr, 1, 5, 5, 32, 96, 3, 1, False, False, tile=208, seed=73)     # tile far larger than the image
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 8, 32), np.float32), np.zeros((96, 32, 3, 3), np.float32), None, 2, 1,
+                   False, tile=201)  # stride 2 is not a halo case
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 8, 32), np.float32), np.zeros((96, 32, 1, 1), np.float32), None, 1, 0,
+                   False, tile=201)  # 1x1
 
 
 def test_conv_matches_c_oracle(rmr, oracle):

