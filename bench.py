@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--no-profile", action="store_true", help="time the steps without per-kernel HIP events")
     return ap.parse_args()
 
 
@@ -146,22 +147,33 @@ def main():
     cap = rdet.max_cars
     flops_frame = W.flops_per_image("m", 1) + K * W.flops_per_image("m", 12)
 
+    import ctypes as C
+    from rm_radar_amd import _lib
+    phases = {"locate_enqueue": 0.0, "detect": 0.0, "search": 0.0, "pack_gather": 0.0}
+
     def step():
+        t0 = time.perf_counter()
         for f in range(B):  # stream order: the Locator carries temporal state
             loc.update(d_clouds[f])
             loc.cluster()
             loc.keep(f)
+        t1 = time.perf_counter()
         robots, counts = rdet.detect_batch_raw(img_list, rects)
-        import ctypes as C
-        from rm_radar_amd import _lib
+        t2 = time.perf_counter()
         base = C.addressof(robots)
         for f in range(B):
             if counts[f]:
                 ptr = C.cast(base + f * cap * C.sizeof(_lib.Robot), C.POINTER(_lib.Robot))
                 loc.search_raw(ptr, int(counts[f]), frame=f)
+        t3 = time.perf_counter()
         block = torch.from_numpy(rd.pack_records(robots, counts, cap, rank, cap))
         if world > 1:
             block = rd.all_gather_records(block.to(dev))
+        t4 = time.perf_counter()
+        phases["locate_enqueue"] += t1 - t0
+        phases["detect"] += t2 - t1
+        phases["search"] += t3 - t2
+        phases["pack_gather"] += t4 - t3
         return block, counts
 
     def sync_all():
@@ -173,13 +185,23 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    with rmr.profile(local) as prof:
+    for k in phases:
+        phases[k] = 0.0
+    if args.no_profile:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             block, counts = step()
         sync_all()
         dt = time.perf_counter() - t0
-        stats = prof.read()
+        stats = {}
+    else:
+        with rmr.profile(local) as prof:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                block, counts = step()
+            sync_all()
+            dt = time.perf_counter() - t0
+            stats = prof.read()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,6 +241,7 @@ def main():
                          "algorithmic_gflop_per_launch": round(conv["flops"] / max(conv["launches"], 1) / 1e9, 4)},
             "kernels": kernels,
             "end_to_end_tflops": round(flops_frame * frames / dt / 1e12, 2),
+            "host_phase_ms_per_step": {k: round(v / args.steps * 1e3, 2) for k, v in phases.items()},
             "located_last_step": n_located,
         }
 

@@ -28,6 +28,7 @@
 #include "locator.h"
 
 #include <cmath>
+#include <mutex>
 
 namespace rmr {
 
@@ -370,6 +371,131 @@ __global__ __launch_bounds__(256) void cc_assign(const int* __restrict__ counter
     if (i == 0) *slot_n_clusters = counters[2];
     if (i >= n) return;
     fg_cluster[i] = root_id[parent[i]];
+}
+
+// ---- cluster(): the whole connected-components stage in ONE workgroup ---------------------------
+//
+// Foreground lists are small (hundreds to a few thousand points), so six dependent grid launches
+// of near-empty kernels cost more in launch gaps and global atomics than the work itself
+// (cc_pairs alone measured 343 us per frame).  Here one 1024-thread workgroup does init, all-pairs
+// union, flatten, size filter, ranking and id assignment with the union-find forest in LDS
+// (n <= CC_LDS_MAX) -- LDS atomics instead of L2 round trips -- or, for larger n, the same code
+// over the global scratch arrays.
+constexpr int CC_THREADS = 1024;
+constexpr int CC_LDS_MAX = 4096;
+
+// LDS forest: plain (volatile) reads; global forest: L2-served atomic loads, because another
+// thread's atomicCAS executes in L2 and would not refresh a line this CU holds in L1
+template <bool SMALL>
+__device__ __forceinline__ int cc_ld(volatile int* parent, int x) {
+    if (SMALL) return parent[x];
+    return __hip_atomic_load((int*)parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool SMALL>
+__device__ __forceinline__ int cc_find(volatile int* parent, int x) {
+    int p = cc_ld<SMALL>(parent, x);
+    while (p != x) {
+        x = p;
+        p = cc_ld<SMALL>(parent, x);
+    }
+    return x;
+}
+
+template <bool SMALL>
+__device__ void cc_block(int n, const float* __restrict__ xyz, float tol2, int min_size, int max_size,
+                         volatile int* parent, int* csize, int* root_id, int* vroot, int* vsize,
+                         const float* lxyz, int* nvalid, int* __restrict__ fg_cluster) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += CC_THREADS) {
+        parent[i] = i;
+        csize[i] = 0;
+        root_id[i] = -1;
+    }
+    if (tid == 0) *nvalid = 0;
+    __syncthreads();
+    // all pairs j < i; thread-strided i keeps the triangular work balanced across threads
+    const float* src = SMALL ? lxyz : xyz;
+    for (int i = tid; i < n; i += CC_THREADS) {
+        const float ax = src[i * 3 + 0], ay = src[i * 3 + 1], az = src[i * 3 + 2];
+        int my_root = i;
+        for (int j = 0; j < i; ++j) {
+            const float dx = src[j * 3 + 0] - ax, dy = src[j * 3 + 1] - ay, dz = src[j * 3 + 2] - az;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < tol2) {
+                if (cc_ld<SMALL>(parent, j) == my_root) continue;  // already united through a common root
+                int a = i, b = j;
+                for (;;) {
+                    a = cc_find<SMALL>(parent, a);
+                    b = cc_find<SMALL>(parent, b);
+                    if (a == b) break;
+                    if (a < b) {
+                        const int t = a;
+                        a = b;
+                        b = t;
+                    }
+                    if (atomicCAS((int*)parent + a, a, b) == a) break;
+                }
+                my_root = a < b ? a : b;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += CC_THREADS) atomicAdd(csize + cc_find<SMALL>(parent, i), 1);
+    __syncthreads();
+    for (int i = tid; i < n; i += CC_THREADS) {
+        const int r = cc_find<SMALL>(parent, i);
+        if (r == i) {
+            const int s = csize[i];
+            if (s >= min_size && s <= max_size) {
+                const int k = atomicAdd(nvalid, 1);
+                vroot[k] = i;
+                vsize[k] = s;
+            }
+        }
+    }
+    __syncthreads();
+    const int nv = *nvalid;
+    for (int a = tid; a < nv; a += CC_THREADS) {
+        const int ra = vroot[a], sa = vsize[a];
+        int rank = 0;
+        for (int b = 0; b < nv; ++b) {
+            const int sb = vsize[b], rb = vroot[b];
+            if (sb > sa || (sb == sa && rb < ra)) ++rank;
+        }
+        root_id[ra] = rank;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += CC_THREADS) fg_cluster[i] = root_id[cc_find<SMALL>(parent, i)];
+}
+
+__global__ __launch_bounds__(CC_THREADS) void cc_fused(int* __restrict__ counters, const float* __restrict__ xyz,
+                                                       float tol2, int min_size, int max_size,
+                                                       int* g_parent, int* g_csize, int* g_root_id, int* g_vroot,
+                                                       int* g_vsize, int* __restrict__ fg_cluster,
+                                                       int* __restrict__ slot_n_clusters) {
+    extern __shared__ __attribute__((aligned(16))) int cc_lds[];
+    __shared__ int nvalid;
+    const int n = counters[0];
+    if (n <= CC_LDS_MAX) {
+        int* parent = cc_lds;                    // [CC_LDS_MAX]
+        int* csize = cc_lds + CC_LDS_MAX;        // [CC_LDS_MAX]
+        int* root_id = cc_lds + 2 * CC_LDS_MAX;  // [CC_LDS_MAX]
+        int* vroot = cc_lds + 3 * CC_LDS_MAX;    // [CC_LDS_MAX]
+        int* vsize = cc_lds + 4 * CC_LDS_MAX;    // [CC_LDS_MAX]
+        float* lxyz = (float*)(cc_lds + 5 * CC_LDS_MAX);  // [3 * CC_LDS_MAX]
+        for (int i = threadIdx.x; i < 3 * n; i += CC_THREADS) lxyz[i] = xyz[i];
+        __syncthreads();
+        cc_block<true>(n, xyz, tol2, min_size, max_size, parent, csize, root_id, vroot, vsize, lxyz, &nvalid, fg_cluster);
+    } else {
+        cc_block<false>(n, xyz, tol2, min_size, max_size, g_parent, g_csize, g_root_id, g_vroot, g_vsize, nullptr,
+                        &nvalid, fg_cluster);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[2] = nvalid;
+        *slot_n_clusters = nvalid;
+    }
 }
 
 __global__ __launch_bounds__(256) void slot_copy(const int* __restrict__ s_nfg,
@@ -720,12 +846,14 @@ void Locator::cluster() {
     fg_count<<<nblk, 256, 0, stream_>>>(diff_.p, npx_, blk_count_.p);
     fg_scan<<<1, 1024, 0, stream_>>>(blk_count_.p, nblk, blk_offset_.p, mf, counters_.p, cur.n_fg);
     fg_compact<<<nblk, 256, 0, stream_>>>(prm_, diff_.p, npx_, blk_offset_.p, mf, cur.fg_pixel, cur.fg_xyz);
-    cc_init<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p, root_id_.p);
-    cc_pairs<<<gfg, 256, 0, stream_>>>(counters_.p, cur.fg_xyz, prm_.tol2, parent_.p);
-    cc_flatten<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p);
-    cc_valid<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p, prm_.min_cluster, prm_.max_cluster, vroot_.p, vsize_.p);
-    cc_rank<<<gfg, 256, 0, stream_>>>(counters_.p, vroot_.p, vsize_.p, root_id_.p);
-    cc_assign<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, root_id_.p, cur.fg_cluster, cur.n_clusters);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)cc_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * CC_LDS_MAX * 4);
+    });
+    (void)gfg;
+    cc_fused<<<1, CC_THREADS, 8 * CC_LDS_MAX * sizeof(int), stream_>>>(
+        counters_.p, cur.fg_xyz, prm_.tol2, prm_.min_cluster, prm_.max_cluster, parent_.p, csize_.p, root_id_.p,
+        vroot_.p, vsize_.p, cur.fg_cluster, cur.n_clusters);
     RMR_HIP(hipGetLastError());
 }
 
