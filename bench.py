@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--no-profile", action="store_true", help="time the steps without per-kernel HIP events")
     return ap.parse_args()
 
@@ -208,6 +208,15 @@ def main():
     dt = float(t.item())
 
     n_located = int(((block.view(-1, 12)[:, 9] & 2) != 0).sum().item()) if block.numel() else 0
+    # HBM traffic per conv launch: PMC counters cannot be read from inside this process; the figure
+    # comes from the committed rocprofv3 --pmc passes over this same command (profiles/)
+    traffic, traffic_src = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
+        if B == 64 and K == 4 and args.size == 640:
+            traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/r01_pmc_conv_traffic.json"
+    except (OSError, KeyError, ValueError):
+        pass
     result = None
     if rank == 0:
         frames = B * args.steps * world
@@ -235,7 +244,9 @@ def main():
                        "streams_per_gpu": 1, "gflop_per_frame": round(flops_frame / 1e9, 3)},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_f16", "achieved": round(ach, 2),
                          "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(conv.get("bytes", 0.0) / max(conv["launches"], 1)),
                          "launches_per_step": conv["launches"] / max(args.steps, 1),
                          "avg_launch_ms": round(conv["total_ms"] / max(conv["launches"], 1), 5),
                          "algorithmic_gflop_per_launch": round(conv["flops"] / max(conv["launches"], 1) / 1e9, 4)},

@@ -95,6 +95,10 @@ class Yolov8 {
     // autotuned kernel choice per (op, images in the launch): >= 100 = conv_dma tile id + 100
     std::map<std::pair<int, int>, int> tuned_;
     bool autotune_ = true;
+    bool tuned_dirty_ = false;
+    std::string tune_path_;  // '<pack>.tune': choices persist like the reference's engine cache
+    void load_tuning();
+    void save_tuning();
 };
 
 }  // namespace rmr

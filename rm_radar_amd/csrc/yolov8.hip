@@ -305,6 +305,8 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
         a_off += f.h * f.w;
     }
 
+    tune_path_ = pack_path + ".tune";
+    if (autotune_) load_tuning();
     arena_.alloc(arena_halves_ * chunk_);
     arena32_.alloc(arena_floats_ * chunk_);
     input_.alloc((size_t)max_batch_ * H * W * 8);
@@ -364,6 +366,32 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     return best;
 }
 
+// The tuning result is cached next to the weight pack, as the reference caches its TensorRT
+// engine next to the ONNX file (detector.cpp:74-99).  One line per entry: "op n choice" after a header with the op count and input size.
+void Yolov8::load_tuning() {
+    std::ifstream f(tune_path_);
+    if (!f) return;
+    std::string tag;
+    int version = 0, n_ops = 0, w = 0, h = 0;
+    f >> tag >> version >> n_ops >> w >> h;
+    if (tag != "rmr-tune" || version != 2 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_) return;
+    int op, n, choice;
+    while (f >> op >> n >> choice) {
+        if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV) continue;
+        const bool ok = choice >= 200 ? choice - 200 < conv_halo_num_tiles()
+                      : choice >= 100 ? choice - 100 < conv_dma_num_tiles()
+                                      : choice >= 0 && choice < conv_num_tiles();
+        if (ok) tuned_[{op, n}] = choice;
+    }
+}
+
+void Yolov8::save_tuning() {
+    std::ofstream f(tune_path_, std::ios::trunc);
+    if (!f) return;  // read-only location: tune again next time
+    f << "rmr-tune 2 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << "\n";
+    for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
+}
+
 void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
     const Op& op = ops_[op_index];
     auto hptr = [&](const View& v) { return arena_.p + v.off * chunk_; };
@@ -411,7 +439,10 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
             }
             auto key = std::make_pair(op_index, n);
             auto it = tuned_.find(key);
-            if (it == tuned_.end()) it = tuned_.emplace(key, tune_conv(s, a)).first;
+            if (it == tuned_.end()) {
+                it = tuned_.emplace(key, tune_conv(s, a)).first;
+                tuned_dirty_ = true;
+            }
             if (it->second >= 200)
                 launch_conv_halo(ctx_, s, a, it->second - 200);
             else if (it->second >= 100)
@@ -440,6 +471,10 @@ void Yolov8::forward(hipStream_t s, int batch) {
     for (int c0 = 0; c0 < batch; c0 += chunk_) {
         const int n = std::min(chunk_, batch - c0);
         for (int i = 0; i < (int)ops_.size(); ++i) run_op(s, i, n, (size_t)c0);
+    }
+    if (tuned_dirty_) {
+        save_tuning();
+        tuned_dirty_ = false;
     }
 }
 
