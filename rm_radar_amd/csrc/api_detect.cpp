@@ -178,6 +178,22 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..: conv_halo tile
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
+        } else if (tile >= 1000) {
+            // 1000 * split + 100 + dma tile: split-K through a private workspace
+            const int split = tile / 1000, t = tile % 1000 - 100;
+            if (t < 0 || t >= conv_dma_num_tiles() || cout_pad % conv_dma_tile(t).bn || !conv_dma_supported(a))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: split-K tile %d cannot run this layer", tile);
+            DevBuf<float> ws;
+            DevBuf<int> cnt;
+            ws.alloc(conv_dma_splitk_ws_floats(a, t, split));
+            cnt.alloc(conv_dma_splitk_tiles(a, t));
+            RMR_HIP(hipMemsetAsync(cnt.p, 0, cnt.n * sizeof(int), ctx.stream));
+            a.split = split;
+            a.splitk_ws = ws.p;
+            a.splitk_cnt = cnt.p;
+            launch_conv_dma(ctx, ctx.stream, a, t);
+            launch_conv_dma(ctx, ctx.stream, a, t);  // twice: the counters must re-arm themselves
+            RMR_HIP(hipStreamSynchronize(ctx.stream));
         } else if (tile >= 200) {
             const int t = tile - 200;
             if (t >= conv_halo_num_tiles() || !conv_halo_supported(a, t))

@@ -87,8 +87,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int xcd = blockIdx.x & 7;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int m0 = (lid / nt_count) * BM;
-    const int n0 = (lid % nt_count) * BN;
+    // split-K: `split` consecutive logical ids (same XCD) share one output tile
+    const int split = a.split > 1 ? a.split : 1;
+    const int tile_id = lid / split;
+    const int zsplit = lid - tile_id * split;
+    const int m0 = (tile_id / nt_count) * BM;
+    const int n0 = (tile_id % nt_count) * BN;
 
     // raw buffer descriptors {base lo, base hi (stride 0), num_records, flags}
     // (readfirstlane makes their uniformity provable, so they are allocated in SGPRs)
@@ -141,9 +145,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
     // both BK, so (row & 15) -- hence the swizzle key and lhalf -- is the same for all its slots
     static_assert((RPD * NW) % 16 == 0, "swizzle key must not depend on the slot");
 
+    // K slices [kt_begin, kt_end) of this workgroup (all of them unless split-K)
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int kt_begin = (int)((long)nk_all * zsplit / split);
+    const int nk = (int)((long)nk_all * (zsplit + 1) / split);  // == kt_end
     // wave-uniform position of the next 32-channel half-slice in the filter window
-    int k_ci = 0, k_kw = 0, k_kh = 0;
-    const int nk = (a.K + BK - 1) / BK;
+    int k_ci, k_kw, k_kh;
+    {
+        const int k = kt_begin * BK;
+        k_ci = k % a.Cin;
+        const int t = k / a.Cin;
+        k_kw = t % a.KW;
+        k_kh = t / a.KW;
+    }
 
     auto issue = [&](int kt, int stage) {
         const bool live = kt < nk;  // slots past the last slice are issued as no-ops (constant vmcnt)
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
 
     // prologue: STAGES-1 slices in flight
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) issue(s, s);
+    for (int s = 0; s < STAGES - 1; ++s) issue(kt_begin + s, s);
 
     // fragment addressing: row (lane & 15) of a 16-row block, logical 16-byte chunk ks*4 + (lane >> 4)
     const int frow = lane & 15;
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
     auto now = [&]() -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
 
     int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt_begin; kt < nk; ++kt) {
         const long long c0 = now();
         // slice kt has landed for this wave once at most STAGES-2 newer slices are outstanding
         wait_vmcnt<(STAGES - 2) * NI>();
@@ -255,6 +269,49 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
         a.timing[4] = t_mfma, a.timing[5] = nk;
     }
     wait_vmcnt<0>();  // the trailing no-op slots
+
+    // ---- split-K: partial tiles meet in the workspace; the last arriver reduces them --------
+    if (split > 1) {
+        __shared__ int is_last;
+        constexpr int TILE_F4 = NW * MREP * NREP * 64;  // float4 per partial tile
+        float4* ws = (float4*)a.splitk_ws + ((size_t)tile_id * split + zsplit) * TILE_F4;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+                ws[((wave * MREP + i) * NREP + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        // publish: every wave drains its stores, one lane releases at agent scope, then the ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(a.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = ticket == split - 1;
+            if (is_last) {
+                __hip_atomic_store(a.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+        __syncthreads();
+        if (!is_last) return;
+        // sum ALL partials (its own re-read from the workspace) in slice order: the result does not
+        // depend on which workgroup happened to arrive last -- run-to-run deterministic
+        const float4* wall = (const float4*)a.splitk_ws + (size_t)tile_id * split * TILE_F4;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < split; ++z) {
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) {
+                    const float4 p = wall[(size_t)z * TILE_F4 + ((wave * MREP + i) * NREP + j) * 64 + lane];
+                    acc[i][j][0] += p.x, acc[i][j][1] += p.y, acc[i][j][2] += p.z, acc[i][j][3] += p.w;
+                }
+        }
+    }
 
     // ---- epilogue: bias, SiLU, residual, store 4 consecutive channels per lane ----
     const int px = lane & 15;
@@ -346,6 +403,18 @@ const DmaTile kDmaTiles[] = {
     DTILE(4, 2, 4, 4, 2, 64),  // 31: 256 x 128 (8 waves)
     DTILE(4, 2, 2, 9, 2, 64),  // 32: 128 x 288 (8 waves)
     DTILE(4, 2, 2, 6, 3, 64),  // 33: 128 x 192 (8 waves)
+    // deep rings for small grids (batch 1..4): the K loop of a lone workgroup per CU is paced by
+    // DMA latency / (STAGES - 1), and LDS is free at that occupancy
+    DTILE(2, 2, 2, 2, 8, 32),  // 34:  64 x 64, 8 stages
+    DTILE(2, 2, 2, 3, 8, 32),  // 35:  64 x 96
+    DTILE(4, 1, 1, 2, 8, 32),  // 36:  64 x 32
+    DTILE(2, 2, 2, 4, 8, 32),  // 37:  64 x 128
+    DTILE(2, 2, 4, 3, 6, 32),  // 38: 128 x 96
+    DTILE(2, 2, 2, 2, 5, 64),  // 39:  64 x 64, BK 64
+    DTILE(2, 2, 2, 3, 5, 64),  // 40:  64 x 96, BK 64
+    DTILE(4, 1, 1, 2, 6, 64),  // 41:  64 x 32, BK 64
+    DTILE(2, 2, 1, 2, 8, 32),  // 42:  32 x 64
+    DTILE(2, 2, 1, 3, 8, 32),  // 43:  32 x 96
 };
 constexpr int kNumDmaTiles = sizeof(kDmaTiles) / sizeof(kDmaTiles[0]);
 
@@ -400,7 +469,13 @@ void launch_conv_dma(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
         for (const DmaTile& d : kDmaTiles)
             (void)hipFuncSetAttribute((const void*)d.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_bytes);
     });
-    const int grid = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    const int tiles = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    if (a.split > 1) {
+        const int nk_all = (a.K + t.bk - 1) / t.bk;
+        if (a.split > nk_all) a.split = nk_all;
+        if (!a.splitk_ws || !a.splitk_cnt) fail(RMR_ERR_LOGIC, "conv_dma: split-K needs a workspace");
+    }
+    const int grid = tiles * (a.split > 1 ? a.split : 1);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
     static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
@@ -409,13 +484,23 @@ void launch_conv_dma(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     const char* pname = "conv_igemm_f16";
     if (per_layer && ctx.prof.on) {
         char buf[48];
-        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d d%d", a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
+        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d d%d/%d", a.M, a.Cout_pad, a.K, a.KH, a.stride, tile, a.split > 1 ? a.split : 1);
         std::lock_guard<std::mutex> lk(name_mu);
         pname = names.emplace(buf, buf).first->second.c_str();
     }
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
     t.kernel<<<grid, t.threads, t.lds_bytes, stream>>>(a);
     RMR_HIP(hipGetLastError());
+}
+
+size_t conv_dma_splitk_ws_floats(const ConvArgs& a, int tile, int split) {
+    const DmaTile& t = kDmaTiles[tile];
+    const size_t tiles = (size_t)((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    return tiles * split * (size_t)t.bm * t.bn;
+}
+int conv_dma_splitk_tiles(const ConvArgs& a, int tile) {
+    const DmaTile& t = kDmaTiles[tile];
+    return ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
 }
 
 int conv_dma_num_tiles() { return kNumDmaTiles; }

@@ -26,6 +26,12 @@ struct ConvArgs {
     int act;            // 1 = SiLU
     unsigned in_bytes;  // bytes addressable from `in` (buffer-load bounds: reads past it return 0)
     unsigned wt_bytes;  // bytes of the packed weights
+    // split-K (conv_dma only): `split` workgroups share one output tile, each accumulating a
+    // contiguous range of K slices; partial tiles meet in splitk_ws and the last arriver (ticket in
+    // splitk_cnt, which it resets to 0) reduces them and runs the epilogue.  split <= 1: off.
+    int split;
+    float* splitk_ws;
+    int* splitk_cnt;
     long long* timing;  // debug: per-phase cycle totals of one wave (RMR_CONV_TIMING), else null
     double flops;       // algorithmic FLOPs of this launch (true channel counts), for profiling
 };
@@ -46,6 +52,9 @@ int conv_dma_num_tiles();
 ConvTile conv_dma_tile(int id);
 int conv_dma_pick_tile(int M, int cout_pad, int num_cus);
 void launch_conv_dma(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+// workspace floats / counters a split-K launch of `tile` needs for this layer
+size_t conv_dma_splitk_ws_floats(const ConvArgs& a, int tile, int split);
+int conv_dma_splitk_tiles(const ConvArgs& a, int tile);
 // halo-staged 3x3 / stride-1 variant (conv_halo.hip): the input range is fetched once per 32-channel
 // chunk and reused by all nine taps
 int conv_halo_num_tiles();

@@ -92,10 +92,15 @@ class Yolov8 {
     DevBuf<float> arena32_;
     DevBuf<__half> input_;
     DevBuf<float> output_;
-    // autotuned kernel choice per (op, images in the launch): >= 100 = conv_dma tile id + 100
+    // autotuned kernel choice per (op, images in the launch): 0..99 conv_igemm tile, 100..199
+    // conv_dma tile, 200..299 conv_halo tile; + 1000 * split for split-K (conv_dma only)
     std::map<std::pair<int, int>, int> tuned_;
     bool autotune_ = true;
     bool tuned_dirty_ = false;
+    // split-K workspace (partial tiles) and re-arming ticket counters, shared by all layers
+    DevBuf<float> splitk_ws_;
+    DevBuf<int> splitk_cnt_;
+    void launch_choice(hipStream_t s, ConvArgs a, int choice);
     std::string tune_path_;  // '<pack>.tune': choices persist like the reference's engine cache
     void load_tuning();
     void save_tuning();

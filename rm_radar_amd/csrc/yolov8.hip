@@ -20,6 +20,9 @@
 
 namespace rmr {
 
+constexpr size_t kSplitKWsFloats = 16u << 20;  // 64 MiB of split-K partial tiles
+constexpr int kSplitKMaxTiles = 8192;
+
 // ---- weight pack ---------------------------------------------------------------------------------
 
 WeightPack WeightPack::load(const std::string& path) {
@@ -305,6 +308,9 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
         a_off += f.h * f.w;
     }
 
+    splitk_ws_.alloc(kSplitKWsFloats);
+    splitk_cnt_.alloc(kSplitKMaxTiles);
+    RMR_HIP(hipMemset(splitk_cnt_.p, 0, kSplitKMaxTiles * sizeof(int)));
     tune_path_ = pack_path + ".tune";
     if (autotune_) load_tuning();
     arena_.alloc(arena_halves_ * chunk_);
@@ -321,6 +327,22 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
 // tiles) on the live buffers and returns the fastest.  A conv launch is idempotent (its output
 // slice never aliases its input or residual slice), so re-running it is harmless.  Runs once per
 // (layer, batch) -- the analogue of the reference's TensorRT engine build (detector.cpp:177-243).
+void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
+    const int split = choice / 1000, c = choice % 1000;
+    if (c >= 200) {
+        launch_conv_halo(ctx_, s, a, c - 200);
+    } else if (c >= 100) {
+        if (split > 1) {
+            a.split = split;
+            a.splitk_ws = splitk_ws_.p;
+            a.splitk_cnt = splitk_cnt_.p;
+        }
+        launch_conv_dma(ctx_, s, a, c - 100);
+    } else {
+        launch_conv(ctx_, s, a, c);
+    }
+}
+
 int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     std::vector<int> cands;
     for (int t = 0; t < conv_num_tiles(); ++t)
@@ -331,6 +353,20 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (conv_halo_supported(a, -1))
         for (int t = 0; t < conv_halo_num_tiles(); ++t)
             if (conv_halo_supported(a, t)) cands.push_back(200 + t);
+    // split-K variants where the plain grid cannot fill the chip (small batches)
+    if (conv_dma_supported(a))
+        for (int t = 0; t < conv_dma_num_tiles(); ++t) {
+            const ConvTile ct = conv_dma_tile(t);
+            if (a.Cout_pad % ct.bn || ct.bm * ct.bn > 128 * 128) continue;
+            const int tiles = conv_dma_splitk_tiles(a, t);
+            const int nk = (a.K + ct.bk - 1) / ct.bk;
+            if (tiles >= ctx_.num_cus || tiles > kSplitKMaxTiles) continue;
+            for (int split : {2, 3, 4, 6, 9, 12, 18}) {
+                if (split > nk / 2 || (long)tiles * split > 3L * ctx_.num_cus) break;
+                if (conv_dma_splitk_ws_floats(a, t, split) > kSplitKWsFloats) break;
+                cands.push_back(1000 * split + 100 + t);
+            }
+        }
     hipEvent_t e0, e1;
     RMR_HIP(hipEventCreate(&e0));
     RMR_HIP(hipEventCreate(&e1));
@@ -340,18 +376,14 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     float best_ms = 1e30f;
     for (int c : cands) {
         // skip tiles that would leave most of the chip idle or are hopelessly oversized
-        const ConvTile t = c >= 200 ? conv_halo_tile(c - 200) : c >= 100 ? conv_dma_tile(c - 100) : conv_tile(c);
+        const int cc = c % 1000;
+        const ConvTile t = cc >= 200 ? conv_halo_tile(cc - 200) : cc >= 100 ? conv_dma_tile(cc - 100) : conv_tile(cc);
         const long blocks = (long)((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
         if (t.bm >= 256 && blocks < ctx_.num_cus / 2 && a.M > 64) continue;
         float ms_min = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
             RMR_HIP(hipEventRecord(e0, s));
-            if (c >= 200)
-                launch_conv_halo(ctx_, s, a, c - 200);
-            else if (c >= 100)
-                launch_conv_dma(ctx_, s, a, c - 100);
-            else
-                launch_conv(ctx_, s, a, c);
+            launch_choice(s, a, c);
             RMR_HIP(hipEventRecord(e1, s));
             RMR_HIP(hipEventSynchronize(e1));
             float ms = 0;
@@ -374,13 +406,14 @@ void Yolov8::load_tuning() {
     std::string tag;
     int version = 0, n_ops = 0, w = 0, h = 0;
     f >> tag >> version >> n_ops >> w >> h;
-    if (tag != "rmr-tune" || version != 2 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_) return;
+    if (tag != "rmr-tune" || version != 3 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_) return;
     int op, n, choice;
     while (f >> op >> n >> choice) {
         if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV) continue;
-        const bool ok = choice >= 200 ? choice - 200 < conv_halo_num_tiles()
-                      : choice >= 100 ? choice - 100 < conv_dma_num_tiles()
-                                      : choice >= 0 && choice < conv_num_tiles();
+        const int c = choice % 1000, split = choice / 1000;
+        const bool ok = choice >= 0 && split <= 64 && (split == 0 || (c >= 100 && c < 200)) &&
+                        (c >= 200 ? c - 200 < conv_halo_num_tiles()
+                                  : c >= 100 ? c - 100 < conv_dma_num_tiles() : c < conv_num_tiles());
         if (ok) tuned_[{op, n}] = choice;
     }
 }
@@ -388,7 +421,7 @@ void Yolov8::load_tuning() {
 void Yolov8::save_tuning() {
     std::ofstream f(tune_path_, std::ios::trunc);
     if (!f) return;  // read-only location: tune again next time
-    f << "rmr-tune 2 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << "\n";
+    f << "rmr-tune 3 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << "\n";
     for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
 }
 
@@ -443,12 +476,7 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
                 it = tuned_.emplace(key, tune_conv(s, a)).first;
                 tuned_dirty_ = true;
             }
-            if (it->second >= 200)
-                launch_conv_halo(ctx_, s, a, it->second - 200);
-            else if (it->second >= 100)
-                launch_conv_dma(ctx_, s, a, it->second - 100);
-            else
-                launch_conv(ctx_, s, a, it->second);
+            launch_choice(s, a, it->second);
             break;
         }
         case OP_SPPF:

@@ -100,6 +100,17 @@ def test_conv_dma_every_tile(rmr):
                    False, tile=100)  # Cin = 48 is not a multiple of 32
 
 
+def test_conv_dma_split_k(rmr):
+    # split-K: several workgroups share an output tile, the last arriver reduces (ticket counter
+    # re-arms itself: the hook launches twice).  tile = 1000 * split + 100 + dma tile
+    for split in (2, 3, 4, 9):
+        run_case(rmr, 1, 20, 20, 192, 192, 3, 1, True, True, tile=1000 * split + 100 + 6, seed=split)   # 64 x 64
+        run_case(rmr, 1, 40, 40, 96, 96, 3, 1, True, False, tile=1000 * split + 100 + 2, seed=10 + split)  # 64 x 96
+        run_case(rmr, 2, 9, 11, 64, 32, 1, 1, False, False, tile=1000 * min(split, 2) + 100 + 13, seed=20 + split)
+    run_case(rmr, 1, 20, 20, 288, 288, 3, 1, True, True, tile=1000 * 6 + 100 + 24, seed=31)            # BK = 64
+    run_case(rmr, 4, 40, 40, 192, 192, 3, 1, True, True, tile=1000 * 3 + 100 + 0, seed=32)             # 128 x 96, 100 tiles
+
+
 def test_conv_halo_every_tile(rmr):
     # halo-staged 3x3 / stride-1 kernel (conv_halo.hip): tile ids 200..; input range staged once,
     # taps are row shifts, image borders (and image-to-image boundaries inside a tile) are masked
