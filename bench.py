@@ -120,7 +120,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is always created, also for one
+    # rank, so the RCCL path is exercised by every launcher-driven run
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
@@ -167,8 +170,8 @@ def main():
                 loc.search_raw(ptr, int(counts[f]), frame=f)
         t3 = time.perf_counter()
         block = torch.from_numpy(rd.pack_records(robots, counts, cap, rank, cap))
-        if world > 1:
-            block = rd.all_gather_records(block.to(dev))
+        if use_dist:
+            block = rd.all_gather_records(block.to(dev), force=True)
         t4 = time.perf_counter()
         phases["locate_enqueue"] += t1 - t0
         phases["detect"] += t2 - t1
@@ -178,7 +181,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -203,7 +206,7 @@ def main():
             dt = time.perf_counter() - t0
             stats = prof.read()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -283,7 +286,7 @@ def main():
         if "cpu_baseline" not in result:
             result["cpu_baseline"] = None
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -73,12 +73,14 @@ def unpack_records(block: np.ndarray):
     return res
 
 
-def all_gather_records(block, group=None):
+def all_gather_records(block, group=None, force=False):
     """block: torch tensor [n_frames, max_per_frame, 12] on this rank's device (or CPU for gloo).
     Returns [world, n_frames, max_per_frame, 12].  One collective per batch of frames."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return block.unsqueeze(0)
+    if dist.get_world_size(group) == 1 and not force:
         return block.unsqueeze(0)
     world = dist.get_world_size(group)
     block = block.contiguous()
