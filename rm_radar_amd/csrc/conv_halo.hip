@@ -38,8 +38,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BSTAGES = 3;       // weight-slice ring
-constexpr int A_SLOTS = 4;       // input-range DMA instructions per slice (taps 0..7 carry them)
-constexpr int A_MAX_ROWS = A_SLOTS * 8 * 16;  // 512 LDS rows
 
 __device__ __forceinline__ float silu_h(float v) { return v / (1.0f + __expf(-v)); }
 
@@ -58,7 +56,8 @@ __device__ __forceinline__ void wait_vm() {
 // chunk permutation key of an LDS row (see header)
 __device__ __forceinline__ int hkey(int row) { return ((row >> 2) & 1) << 1; }
 
-template <int WM, int WN, int MREP, int NREP>
+// A_SLOTS: input-range DMA instructions per slice (taps 0..7 carry them) => up to A_SLOTS*128 rows
+template <int WM, int WN, int MREP, int NREP, int A_SLOTS>
 __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a, const int a_rows) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 16;
@@ -111,7 +110,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
         const int row = (q - A_SLOTS) * 16 + lrow;
         w_off[j] = (q >= A_SLOTS && q < SLOTS) ? ((n0 + row) * a.Kp + lchunk * 8) * 2 : 0;
     }
-    const int chunks = a.Cin / 32;
+    const int chunks = (a.Cin + 31) / 32;  // the last chunk may be partial (Cin % 32 != 0): the
+    // missing channels are zero-filled on BOTH operands (a weight slice must not run into the next tap)
+    const int ch_in_chunk = lchunk * 8;
 
     const unsigned scratch = sgpr(lds0 + b_base + BSTAGES * B_STAGE_BYTES);  // idle slots land here
 
@@ -133,13 +134,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
                 const int p = lo + ia * 16 + lrow;  // input pixel of this lane's row
                 if (a_live && ia < na) {
                     unsigned off = OOB;
-                    if (p >= 0 && p < npix) off = (unsigned)((p * a.in_cs + a.in_co + (cc + 1) * 32 + lchunk * 8) * 2);
+                    if (p >= 0 && p < npix && (cc + 1) * 32 + ch_in_chunk < a.Cin)
+                        off = (unsigned)((p * a.in_cs + a.in_co + (cc + 1) * 32 + lchunk * 8) * 2);
                     dma16h(in_rsrc, sgpr(lds0 + ((cc + 1) & 1) * a_buf_bytes + ia * 1024), off);
                 } else {
                     dma16h(in_rsrc, scratch, OOB);
                 }
             } else if (q < SLOTS) {
-                const unsigned off = w_live ? (unsigned)(w_off[j] + wdelta) : OOB;
+                const unsigned off = (w_live && ks_c * 32 + ch_in_chunk < a.Cin) ? (unsigned)(w_off[j] + wdelta) : OOB;
                 dma16h(wt_rsrc, sgpr(lds0 + b_base + w_stage * B_STAGE_BYTES + (q - A_SLOTS) * 1024), off);
             } else {
                 dma16h(wt_rsrc, scratch, OOB);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     for (int ia = wave; ia < na; ia += NW) {
         const int p = lo + ia * 16 + lrow;
         unsigned off = OOB;
-        if (p >= 0 && p < npix) off = (unsigned)((p * a.in_cs + a.in_co + lchunk * 8) * 2);
+        if (p >= 0 && p < npix && ch_in_chunk < a.Cin) off = (unsigned)((p * a.in_cs + a.in_co + lchunk * 8) * 2);
         dma16h(in_rsrc, sgpr(lds0 + ia * 1024), off);
     }
     // weight slices 0 .. BSTAGES-2 (taps 0, 1 of chunk 0)
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
             const int q = wave + NW * j;
             if (q >= A_SLOTS && q < SLOTS)
                 dma16h(wt_rsrc, sgpr(lds0 + b_base + s * B_STAGE_BYTES + (q - A_SLOTS) * 1024),
-                       (unsigned)(w_off[j] + s * a.Cin * 2));
+                       ch_in_chunk < a.Cin ? (unsigned)(w_off[j] + s * a.Cin * 2) : OOB);
         }
     }
     wait_vm<0>();
@@ -271,12 +273,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
 }
 
 struct HaloTile {
-    int bm, bn, threads;
+    int bm, bn, threads, max_rows;
     void (*kernel)(const ConvArgs, int);
 };
 
 #define HTILE(WM, WN, MR, NR) \
-    { WM * MR * 16, WN * NR * 16, WM * WN * 64, conv_halo_kernel<WM, WN, MR, NR> }
+    { WM * MR * 16, WN * NR * 16, WM * WN * 64, 4 * 128, conv_halo_kernel<WM, WN, MR, NR, 4> }
+#define HTILE_WIDE(WM, WN, MR, NR) \
+    { WM * MR * 16, WN * NR * 16, WM * WN * 64, 6 * 128, conv_halo_kernel<WM, WN, MR, NR, 6> }
 
 const HaloTile kHaloTiles[] = {
     HTILE(4, 2, 4, 6),  // 0: 256 x 192
@@ -290,6 +294,11 @@ const HaloTile kHaloTiles[] = {
     HTILE(2, 2, 4, 3),  // 8: 128 x 96 (4 waves)
     HTILE(2, 2, 4, 4),  // 9: 128 x 128 (4 waves)
     HTILE(4, 1, 4, 6),  // 10: 256 x 96 (4 waves)
+    // wide feature maps (W = 160: 322 halo rows) and N = 48: a longer input range per chunk
+    HTILE_WIDE(4, 1, 4, 3),  // 11: 256 x 48 (4 waves)
+    HTILE_WIDE(8, 1, 2, 3),  // 12: 256 x 48 (8 waves)
+    HTILE_WIDE(4, 2, 4, 3),  // 13: 256 x 96 (8 waves)
+    HTILE_WIDE(8, 1, 3, 3),  // 14: 384 x 48 (8 waves)
 };
 constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
 
@@ -304,11 +313,11 @@ int conv_halo_num_tiles() { return kNumHaloTiles; }
 ConvTile conv_halo_tile(int id) { return ConvTile{kHaloTiles[id].bm, kHaloTiles[id].bn, 32}; }
 
 bool conv_halo_supported(const ConvArgs& a, int tile) {
-    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 32) return false;
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 8 || a.Cin < 32) return false;
     if (a.Ho != a.H || a.Wo != a.W) return false;
     if (tile < 0) return true;
     const HaloTile& t = kHaloTiles[tile];
-    return a.Cout_pad % t.bn == 0 && halo_rows(t.bm, a.W) <= A_MAX_ROWS && halo_lds_bytes(t, a.W) <= 160 * 1024;
+    return a.Cout_pad % t.bn == 0 && halo_rows(t.bm, a.W) <= t.max_rows && halo_lds_bytes(t, a.W) <= 160 * 1024;
 }
 
 void launch_conv_halo(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {

@@ -115,7 +115,7 @@ def test_conv_halo_every_tile(rmr):
     # halo-staged 3x3 / stride-1 kernel (conv_halo.hip): tile ids 200..; input range staged once,
     # taps are row shifts, image borders (and image-to-image boundaries inside a tile) are masked
     tiles = [(256, 192), (256, 96), (256, 288), (256, 128), (256, 256), (256, 64), (128, 192), (128, 288),
-             (128, 96), (128, 128), (256, 96)]
+             (128, 96), (128, 128), (256, 96), (256, 48), (256, 48), (256, 96), (384, 48)]
     for t, (bm, bn) in enumerate(tiles):
         run_case(rmr, 3, 20, 20, 64, bn, 3, 1, True, True, tile=200 + t, seed=t)          # 3 images per ~5 tiles
         run_case(rmr, 1, 19, 23, 32, bn * 2, 3, 1, True, False, tile=200 + t, seed=40 + t)  # odd W, ragged M
@@ -123,6 +123,9 @@ def test_conv_halo_every_tile(rmr):
     run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, True, tile=201, seed=71)     # W = 80: 418-row input range
     run_case(rmr, 2, 20, 20, 288, 288, 3, 1, True, True, tile=207, seed=72)   # 9 chunks
     run_case(rmr, 1, 5, 5, 32, 96, 3, 1, False, False, tile=208, seed=73)     # tile far larger than the image
+    run_case(rmr, 1, 160, 160, 48, 48, 3, 1, True, True, tile=211, seed=74)   # Cin 48: partial channel chunk, W = 160
+    run_case(rmr, 2, 33, 29, 48, 96, 3, 1, True, False, tile=213, seed=75)    # Cin 48, odd sizes
+    run_case(rmr, 1, 24, 24, 40, 48, 3, 1, False, False, tile=212, seed=76)   # Cin 40 (8-channel granularity)
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 8, 8, 32), np.float32), np.zeros((96, 32, 3, 3), np.float32), None, 2, 1,
                    False, tile=201)  # stride 2 is not a halo case
