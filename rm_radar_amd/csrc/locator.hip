@@ -13,10 +13,11 @@
 //                            ring oldest -> newest (Q14), write the foreground image;
 //   cluster()  fg_count / fg_scan / fg_compact : row-major ordered compaction of the
 //                            non-zero foreground pixels + cameraToLidar (Q16);
-//              cc_*          Euclidean clustering = connected components of
+//              cc_fused      Euclidean clustering = connected components of
 //                            "squared distance < tolerance^2" by lock-free union-find
-//                            (hook the larger root under the smaller), size filter,
-//                            ids ordered by (size desc, lowest member index) (Q17);
+//                            (hook the larger root under the smaller) in ONE workgroup
+//                            with the forest in LDS, size filter, ids ordered by
+//                            (size desc, lowest member index) (Q17);
 //   search()   loc_search    one workgroup per robot over the compact foreground list:
 //                            LDS bucket histogram, first-max winner (-1 wins ties, Q18),
 //                            f64 tree-sum centroid, lidar->world, mm -> m.
@@ -235,142 +236,6 @@ __global__ __launch_bounds__(256) void fg_compact(LocParams P, const float* __re
             ++dst;
         }
     }
-}
-
-// ---- cluster(): connected components ---------------------------------------------------------
-
-__device__ __forceinline__ int ld_parent(const int* parent, int i) {
-    return __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ int find_root(const int* parent, int x) {
-    int p = ld_parent(parent, x);
-    while (p != x) {
-        x = p;
-        p = ld_parent(parent, x);
-    }
-    return x;
-}
-
-// Hook the larger root under the smaller: every tree's root is its lowest member index.
-__device__ __forceinline__ void unite(int* parent, int a, int b) {
-    for (;;) {
-        a = find_root(parent, a);
-        b = find_root(parent, b);
-        if (a == b) return;
-        if (a < b) {
-            const int t = a;
-            a = b;
-            b = t;
-        }
-        if (atomicCAS(parent + a, a, b) == a) return;
-    }
-}
-
-__global__ __launch_bounds__(256) void cc_init(const int* __restrict__ counters,
-                                               int* __restrict__ parent, int* __restrict__ csize,
-                                               int* __restrict__ root_id) {
-    const int n = counters[0];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        parent[i] = i;
-        csize[i] = 0;
-        root_id[i] = -1;
-    }
-}
-
-__global__ __launch_bounds__(256) void cc_pairs(const int* __restrict__ counters,
-                                                const float* __restrict__ xyz, float tol2,
-                                                int* __restrict__ parent) {
-    __shared__ float tx[256], ty[256], tz[256];
-    const int n = counters[0];
-    const int blk_base = blockIdx.x * 256;
-    if (blk_base >= n) return;
-    const int i = blk_base + threadIdx.x;
-    float ax = 0, ay = 0, az = 0;
-    if (i < n) {
-        ax = xyz[i * 3 + 0];
-        ay = xyz[i * 3 + 1];
-        az = xyz[i * 3 + 2];
-    }
-    const int jmax = min(n, blk_base + 256);  // pairs j < i only
-    for (int tile = 0; tile < jmax; tile += 256) {
-        const int j = tile + threadIdx.x;
-        if (j < n) {
-            tx[threadIdx.x] = xyz[j * 3 + 0];
-            ty[threadIdx.x] = xyz[j * 3 + 1];
-            tz[threadIdx.x] = xyz[j * 3 + 2];
-        }
-        __syncthreads();
-        if (i < n) {
-            const int m = min(256, i - tile);  // j < i
-            for (int q = 0; q < m; ++q) {
-                const float dx = tx[q] - ax, dy = ty[q] - ay, dz = tz[q] - az;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 < tol2) unite(parent, i, tile + q);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void cc_flatten(const int* __restrict__ counters,
-                                                  int* __restrict__ parent,
-                                                  int* __restrict__ csize) {
-    const int n = counters[0];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int r = find_root(parent, i);
-    atomicAdd(csize + r, 1);
-    // roots keep parent[r] == r; writing a non-root's parent is race-free here because
-    // find_root of any other thread still terminates at the same root
-    if (r != i) __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(256) void cc_valid(int* __restrict__ counters,
-                                                const int* __restrict__ parent,
-                                                const int* __restrict__ csize, int min_size,
-                                                int max_size, int* __restrict__ vroot,
-                                                int* __restrict__ vsize) {
-    const int n = counters[0];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (parent[i] != i) return;
-    const int s = csize[i];
-    if (s >= min_size && s <= max_size) {
-        const int k = atomicAdd(counters + 2, 1);
-        vroot[k] = i;
-        vsize[k] = s;
-    }
-}
-
-// cluster id = rank under (size descending, root ascending)
-__global__ __launch_bounds__(256) void cc_rank(const int* __restrict__ counters,
-                                               const int* __restrict__ vroot,
-                                               const int* __restrict__ vsize,
-                                               int* __restrict__ root_id) {
-    const int nv = counters[2];
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= nv) return;
-    const int ra = vroot[a], sa = vsize[a];
-    int rank = 0;
-    for (int b = 0; b < nv; ++b) {
-        const int sb = vsize[b], rb = vroot[b];
-        if (sb > sa || (sb == sa && rb < ra)) ++rank;
-    }
-    root_id[ra] = rank;
-}
-
-__global__ __launch_bounds__(256) void cc_assign(const int* __restrict__ counters,
-                                                 const int* __restrict__ parent,
-                                                 const int* __restrict__ root_id,
-                                                 int* __restrict__ fg_cluster,
-                                                 int* __restrict__ slot_n_clusters) {
-    const int n = counters[0];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) *slot_n_clusters = counters[2];
-    if (i >= n) return;
-    fg_cluster[i] = root_id[parent[i]];
 }
 
 // ---- cluster(): the whole connected-components stage in ONE workgroup ---------------------------

@@ -360,9 +360,9 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
             if (a.Cout_pad % ct.bn || ct.bm * ct.bn > 128 * 128) continue;
             const int tiles = conv_dma_splitk_tiles(a, t);
             const int nk = (a.K + ct.bk - 1) / ct.bk;
-            if (tiles >= ctx_.num_cus || tiles > kSplitKMaxTiles) continue;
+            if (tiles >= 2 * ctx_.num_cus || tiles > kSplitKMaxTiles) continue;
             for (int split : {2, 3, 4, 6, 9, 12, 18}) {
-                if (split > nk / 2 || (long)tiles * split > 3L * ctx_.num_cus) break;
+                if (split > nk / 2 || (long)tiles * split > 4L * ctx_.num_cus) break;
                 if (conv_dma_splitk_ws_floats(a, t, split) > kSplitKWsFloats) break;
                 cands.push_back(1000 * split + 100 + t);
             }
