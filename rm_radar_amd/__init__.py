@@ -232,7 +232,8 @@ class Detector:
                  input_name="images", input_channels=3, opt_level=3, device=0):
         cfg = _lib.DetectorCfg()
         lib().rmr_detector_cfg_default(C.byref(cfg))
-        self._path = str(engine_path).encode()
+        from .onnx_import import ensure_pack  # detector.cpp:74-99: build from the sibling .onnx when missing
+        self._path = ensure_pack(engine_path).encode()
         cfg.engine_path = self._path
         cfg.classes = classes
         cfg.image_width, cfg.image_height = image_size
@@ -289,7 +290,8 @@ class RobotDetector:
                  device=0, max_frames=1):
         cfg = _lib.RobotDetectorCfg()
         lib().rmr_robot_detector_cfg_default(C.byref(cfg))
-        self._paths = (str(car_engine_path).encode(), str(armor_engine_path).encode())
+        from .onnx_import import ensure_pack
+        self._paths = (ensure_pack(car_engine_path).encode(), ensure_pack(armor_engine_path).encode())
         cfg.car_engine_path, cfg.armor_engine_path = self._paths
         cfg.image_width, cfg.image_height = image_size
         cfg.armor_classes = armor_classes
