@@ -251,7 +251,7 @@ class Detector:
         self.flops_per_image = lib().rmr_detector_flops_per_image(self._h)
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # module globals are gone at interpreter exit
             lib().rmr_detector_destroy(self._h)
             self._h = None
 
@@ -308,7 +308,7 @@ class RobotDetector:
         check(lib().rmr_robot_detector_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # module globals are gone at interpreter exit
             lib().rmr_robot_detector_destroy(self._h)
             self._h = None
 
@@ -380,7 +380,7 @@ class Locator:
         self.hz = lib().rmr_locator_height(self._h)
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # module globals are gone at interpreter exit
             lib().rmr_locator_destroy(self._h)
             self._h = None
 

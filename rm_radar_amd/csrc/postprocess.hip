@@ -1,13 +1,15 @@
-// postprocess.hip -- one fused launch for the reference's transposeKernel + decodeKernel +
-// NMSKernel + host NaN filter + restoreDetection (src/detect/detector.cu:185-360, 522-582;
-// src/detect/detector.cpp:258-268), one 1024-thread workgroup per image.
+// postprocess.hip -- the reference's transposeKernel + decodeKernel + NMSKernel + host NaN filter
+// + restoreDetection (src/detect/detector.cu:185-360, 522-582; src/detect/detector.cpp:258-268)
+// as two launches:
 //
-//   pass 1  read the network output [C][A] directly (coalesced over A -- the transpose is a
-//           pure layout change, Q6), argmax over classes (first max, Q7), keep rows with
-//           !(conf < thresh), compact them IN ANCHOR ORDER with wave ballots + an LDS scan;
-//   pass 2  "any-higher" NMS (Q9) over the k survivors only (k^2 instead of the reference's
-//           8400^2 pair tests), candidates staged through LDS tiles;
-//   pass 3  ordered compaction of the kept rows, restore to source-image pixels, write.
+//   pp_decode  one thread per anchor over the whole batch: read the network output [C][A]
+//              directly (coalesced over A -- the transpose is a pure layout change, Q6), argmax
+//              over classes (first max, Q7), test !(conf < thresh); each wave publishes its ballot
+//              and the passing rows are stored at their anchor position;
+//   pp_nms     one 1024-thread workgroup per image: scan the ballots' popcounts, gather the k
+//              survivors IN ANCHOR ORDER, "any-higher" NMS (Q9) over them only (k^2 instead of the
+//              reference's 8400^2 pair tests) with candidates staged through LDS tiles, ordered
+//              compaction of the kept rows, restore to source-image pixels, write.
 //
 // Bit-exact against the oracle: same f32 operation order, IEEE division, no contraction.
 #include "postprocess.h"
@@ -16,6 +18,7 @@ namespace rmr {
 
 constexpr int PP_THREADS = 1024;
 constexpr int PP_WAVES = PP_THREADS / 64;
+constexpr int NMS_GROUP = 4;  // rows a wave tests per sweep over the other rows
 
 struct Cand {
     float x, y, w, h, label, conf;
@@ -63,78 +66,137 @@ __device__ __forceinline__ int block_rank(bool flag, int* wave_tot, int& total) 
     return before + lane_rank;
 }
 
-__global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
-    const float* __restrict__ net_out, int channels, int anchors, int classes, float nms_thresh,
-    float conf_thresh, const rmr_preparam* __restrict__ pps, Cand* __restrict__ scratch,
+constexpr int PD_THREADS = 256;
+
+__global__ __launch_bounds__(PD_THREADS) void pp_decode_kernel(
+    const float* __restrict__ net_out, int channels, int anchors, int classes, float conf_thresh,
+    Cand* __restrict__ dense, unsigned long long* __restrict__ ballots, int n_words) {
+    const int img = blockIdx.y;
+    const int a = blockIdx.x * PD_THREADS + threadIdx.x;
+    const float* src = net_out + (size_t)img * channels * anchors;
+    bool pass = false;
+    Cand c{};
+    if (a < anchors) {
+        const float cx = src[a];
+        const float cy = src[(size_t)anchors + a];
+        const float w = src[(size_t)2 * anchors + a];
+        const float h = src[(size_t)3 * anchors + a];
+        // detector.cu:230-235: strict '>' keeps the first maximal class.  Scores are fetched
+        // eight at a time so the loads overlap instead of one L2 round trip per class.
+        float best = src[(size_t)4 * anchors + a];
+        int best_j = 0;
+        for (int j0 = 1; j0 < classes; j0 += 8) {
+            float sc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                sc[u] = (j0 + u < classes) ? src[(size_t)(4 + j0 + u) * anchors + a] : -3.0e38f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < classes && sc[u] > best) {
+                    best = sc[u];
+                    best_j = j0 + u;
+                }
+        }
+        // detector.cu:237-238: 0.5 is a double literal
+        c.x = (float)fmax((double)cx - 0.5 * (double)w, 0.0);
+        c.y = (float)fmax((double)cy - 0.5 * (double)h, 0.0);
+        c.w = w;
+        c.h = h;
+        c.label = (float)best_j;
+        c.conf = best;
+        pass = !(best < conf_thresh);  // detector.cu:341
+    }
+    const unsigned long long bal = __ballot(pass);
+    if (pass) dense[(size_t)img * anchors + a] = c;
+    const int word = (blockIdx.x * PD_THREADS + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63) == 0 && word < n_words) ballots[(size_t)img * n_words + word] = bal;
+}
+
+__global__ __launch_bounds__(PP_THREADS) void pp_nms_kernel(
+    const Cand* __restrict__ dense, const unsigned long long* __restrict__ ballots, int n_words,
+    int anchors, float nms_thresh, const rmr_preparam* __restrict__ pps, Cand* __restrict__ scratch,
     rmr_detection* __restrict__ out, int* __restrict__ counts, int cap) {
     __shared__ int wave_tot[PP_WAVES];
-    __shared__ float t_x[PP_THREADS], t_y[PP_THREADS], t_w[PP_THREADS], t_h[PP_THREADS],
-        t_l[PP_THREADS], t_c[PP_THREADS];
+    __shared__ alignas(16) float tbuf[6 * PP_THREADS];
+    float *t_x = tbuf, *t_y = tbuf + PP_THREADS, *t_w = tbuf + 2 * PP_THREADS,
+          *t_h = tbuf + 3 * PP_THREADS, *t_l = tbuf + 4 * PP_THREADS, *t_c = tbuf + 5 * PP_THREADS;
+    int* woff = (int*)tbuf;  // pass 1 only: the tile arrays are not live yet
+    unsigned long long* wbal = (unsigned long long*)(tbuf + PP_THREADS);
+    __shared__ float m_x[PP_THREADS], m_y[PP_THREADS], m_w[PP_THREADS], m_h[PP_THREADS],
+        m_l[PP_THREADS], m_c[PP_THREADS];
+    __shared__ int supp[PP_THREADS];
 
     const int img = blockIdx.x;
-    const float* src = net_out + (size_t)img * channels * anchors;
     Cand* cand = scratch + (size_t)img * anchors;
+    const Cand* src = dense + (size_t)img * anchors;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
 
-    // ---- pass 1: decode + threshold + ordered compaction ----
+    // ---- pass 1: gather the survivors in anchor order ----
+    // Exclusive scan of the ballots' popcounts (kept in LDS), then row r looks its anchor up:
+    // binary search for its word, select its bit.  All k row copies are in flight together.
     int k = 0;
-    for (int base = 0; base < anchors; base += PP_THREADS) {
-        const int a = base + tid;
-        bool pass = false;
-        Cand c{};
-        if (a < anchors) {
-            const float cx = src[a];
-            const float cy = src[(size_t)anchors + a];
-            const float w = src[(size_t)2 * anchors + a];
-            const float h = src[(size_t)3 * anchors + a];
-            // detector.cu:230-235: strict '>' keeps the first maximal class.  Scores are fetched
-            // eight at a time so the loads overlap instead of one L2 round trip per class.
-            float best = src[(size_t)4 * anchors + a];
-            int best_j = 0;
-            for (int j0 = 1; j0 < classes; j0 += 8) {
-                float sc[8];
+    for (int wbase = 0; wbase < n_words; wbase += PP_THREADS) {
+        const int w = wbase + tid;
+        const unsigned long long bal = (w < n_words) ? ballots[(size_t)img * n_words + w] : 0ull;
+        const int cnt = __popcll(bal);
+        int incl = cnt;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    sc[u] = (j0 + u < classes) ? src[(size_t)(4 + j0 + u) * anchors + a] : -3.0e38f;
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (j0 + u < classes && sc[u] > best) {
-                        best = sc[u];
-                        best_j = j0 + u;
-                    }
-            }
-            // detector.cu:237-238: 0.5 is a double literal
-            c.x = (float)fmax((double)cx - 0.5 * (double)w, 0.0);
-            c.y = (float)fmax((double)cy - 0.5 * (double)h, 0.0);
-            c.w = w;
-            c.h = h;
-            c.label = (float)best_j;
-            c.conf = best;
-            pass = !(best < conf_thresh);  // detector.cu:341
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
         }
-        int total;
-        const int r = block_rank(pass, wave_tot, total);
-        if (pass) cand[k + r] = c;
-        k += total;
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int q = 0; q < PP_WAVES; ++q) {
+            const int t = wave_tot[q];
+            before += (q < wid) ? t : 0;
+            all += t;
+        }
+        woff[tid] = before + incl - cnt;  // rows before word wbase + tid, within this chunk
+        wbal[tid] = bal;
+        __syncthreads();
+        for (int r = tid; r < all; r += PP_THREADS) {
+            int lo = 0, hi = PP_THREADS - 1;  // last word with woff <= r
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (woff[mid] <= r) lo = mid; else hi = mid - 1;
+            }
+            unsigned long long bits = wbal[lo];
+            for (int skip = r - woff[lo]; skip > 0; --skip) bits &= bits - 1ull;
+            cand[k + r] = src[(wbase + lo) * 64 + __builtin_ctzll(bits)];
+        }
+        k += all;
+        __syncthreads();  // woff / wbal are rewritten by the next chunk
     }
     __syncthreads();  // cand[] (global) written by this block is read below
     __threadfence_block();
 
     // ---- pass 2 + 3: any-higher NMS, ordered compaction, restore ----
+    // Pair tests are spread over the whole workgroup: each wave takes NMS_GROUP rows at a time and
+    // its 64 lanes stride over the other rows, so a row's fate is an OR over lanes (detector.cu:
+    // 348-356 is an any-quantifier, order does not matter) instead of one long serial loop.
     const rmr_preparam pp = pps[img];
     int n_out = 0;
     for (int base = 0; base < k; base += PP_THREADS) {
-        const int i = base + tid;
-        Cand me{};
-        bool alive = false;
-        if (i < k) {
-            me = cand[i];
-            alive = true;
+        const int mi = min(PP_THREADS, k - base);
+        if (tid < mi) {
+            const Cand o = cand[base + tid];
+            m_x[tid] = o.x;
+            m_y[tid] = o.y;
+            m_w[tid] = o.w;
+            m_h[tid] = o.h;
+            m_l[tid] = o.label;
+            m_c[tid] = o.conf;
         }
+        supp[tid] = 0;
         for (int tile = 0; tile < k; tile += PP_THREADS) {
-            const int j = tile + tid;
-            if (j < k) {
-                const Cand o = cand[j];
+            const int mj = min(PP_THREADS, k - tile);
+            __syncthreads();  // previous tile fully consumed; m_* / supp visible
+            if (tid < mj) {
+                const Cand o = cand[tile + tid];
                 t_x[tid] = o.x;
                 t_y[tid] = o.y;
                 t_w[tid] = o.w;
@@ -143,35 +205,53 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_kernel(
                 t_c[tid] = o.conf;
             }
             __syncthreads();
-            if (alive) {
-                const int m = min(PP_THREADS, k - tile);
-                for (int q = 0; q < m; ++q) {
-                    // detector.cu:348-356
-                    if (t_l[q] == me.label && t_c[q] > me.conf) {
-                        if (iou_xywh(me.x, me.y, me.w, me.h, t_x[q], t_y[q], t_w[q], t_h[q]) >
-                            nms_thresh) {
-                            alive = false;
-                            break;
-                        }
-                    }
+            for (int i0 = wid * NMS_GROUP; i0 < mi; i0 += PP_WAVES * NMS_GROUP) {
+                float ax[NMS_GROUP], ay[NMS_GROUP], aw[NMS_GROUP], ah[NMS_GROUP], al[NMS_GROUP],
+                    ac[NMS_GROUP];
+                bool hit[NMS_GROUP];
+#pragma unroll
+                for (int u = 0; u < NMS_GROUP; ++u) {
+                    const int i = min(i0 + u, mi - 1);
+                    ax[u] = m_x[i];
+                    ay[u] = m_y[i];
+                    aw[u] = m_w[i];
+                    ah[u] = m_h[i];
+                    al[u] = m_l[i];
+                    ac[u] = m_c[i];
+                    hit[u] = false;
+                }
+                for (int q = lane; q < mj; q += 64) {
+                    const float qx = t_x[q], qy = t_y[q], qw = t_w[q], qh = t_h[q], ql = t_l[q],
+                                qc = t_c[q];
+#pragma unroll
+                    for (int u = 0; u < NMS_GROUP; ++u)
+                        hit[u] |= (ql == al[u]) & (qc > ac[u]) &
+                                  (iou_xywh(ax[u], ay[u], aw[u], ah[u], qx, qy, qw, qh) > nms_thresh);
+                }
+#pragma unroll
+                for (int u = 0; u < NMS_GROUP; ++u) {
+                    const bool any = __any(hit[u]);
+                    if (any && lane == 0 && i0 + u < mi) supp[i0 + u] = 1;
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
+        const bool alive = tid < mi && supp[tid] == 0;
         int total;
         const int r = block_rank(alive, wave_tot, total);
         if (alive && n_out + r < cap) {
             // detector.cpp:258-268
             rmr_detection d;
-            d.x = clampf((me.x - pp.dw) * pp.ratio, 0.0f, pp.width);
-            d.y = clampf((me.y - pp.dh) * pp.ratio, 0.0f, pp.height);
-            d.width = clampf(me.w * pp.ratio, 0.0f, pp.width - d.x);
-            d.height = clampf(me.h * pp.ratio, 0.0f, pp.height - d.y);
-            d.label = me.label;
-            d.confidence = me.conf;
+            d.x = clampf((m_x[tid] - pp.dw) * pp.ratio, 0.0f, pp.width);
+            d.y = clampf((m_y[tid] - pp.dh) * pp.ratio, 0.0f, pp.height);
+            d.width = clampf(m_w[tid] * pp.ratio, 0.0f, pp.width - d.x);
+            d.height = clampf(m_h[tid] * pp.ratio, 0.0f, pp.height - d.y);
+            d.label = m_l[tid];
+            d.confidence = m_c[tid];
             out[(size_t)img * cap + n_out + r] = d;
         }
         n_out += total;
+        __syncthreads();  // m_* are rewritten by the next chunk
     }
     if (tid == 0) counts[img] = n_out;
 }
@@ -182,13 +262,23 @@ void launch_postprocess(DeviceCtx& ctx, hipStream_t stream, const float* net_out
                         rmr_detection* out_dev, int* counts_dev, int cap) {
     if (n <= 0) return;
     ProfScope ps(ctx.prof, stream, "postprocess", 0, (double)n * channels * anchors * 4);
-    postprocess_kernel<<<n, PP_THREADS, 0, stream>>>(net_out, channels, anchors, classes,
-                                                     nms_thresh, conf_thresh, pps_dev,
-                                                     (Cand*)scratch, out_dev, counts_dev, cap);
+    // scratch: [n][anchors] dense rows | [n][anchors] gathered rows | [n][n_words] ballots
+    const int n_words = (anchors + 63) / 64;
+    Cand* dense = (Cand*)scratch;
+    Cand* gathered = dense + (size_t)n * anchors;
+    unsigned long long* ballots = (unsigned long long*)(gathered + (size_t)n * anchors);
+    dim3 grid((anchors + PD_THREADS - 1) / PD_THREADS, n);
+    pp_decode_kernel<<<grid, PD_THREADS, 0, stream>>>(net_out, channels, anchors, classes,
+                                                      conf_thresh, dense, ballots, n_words);
+    RMR_HIP(hipGetLastError());
+    pp_nms_kernel<<<n, PP_THREADS, 0, stream>>>(dense, ballots, n_words, anchors, nms_thresh,
+                                                pps_dev, gathered, out_dev, counts_dev, cap);
     RMR_HIP(hipGetLastError());
 }
 
-size_t postprocess_scratch_bytes(int n, int anchors) { return (size_t)n * anchors * sizeof(Cand); }
+size_t postprocess_scratch_bytes(int n, int anchors) {
+    return (size_t)n * anchors * sizeof(Cand) * 2 + (size_t)n * ((anchors + 63) / 64) * 8 + 64;
+}
 
 // ---- transposeKernel stand-in (detector.cu:185-203), only for its known-answer test ----
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,

@@ -126,42 +126,92 @@ def test_constructor_errors(rmr, packs, tmp_path):
         rmr.Detector(str(bad), 1, (640, 640), 1)
 
 
-def _oracle_robot_detect(oracle, refs, img, max_cars, iou_thresh=0.75):
-    """RobotDetector::detect (detector.cpp:413-455) composed from the CPU oracles."""
-    car32, armor32 = refs["car"][0], refs["armor"][0]
-    blob, p = oracle.preprocess(img)
-    cars = oracle.postprocess(car32.forward(blob[None])[0], 1, 0.65, 0.25, p)[:max_cars]
+def _clear_threshold(heads, lo, hi, min_gap=0.04):
+    """A confidence threshold in [lo, hi] in the middle of the widest gap between the oracle's
+    per-anchor best-class scores, so that f16 noise (<= 2e-2) cannot move an anchor across it."""
+    best = np.sort(np.concatenate([h[4:].max(0) for h in heads]))
+    v = np.concatenate([[lo], best[(best > lo) & (best < hi)], [hi]])
+    i = int(np.argmax(np.diff(v)))
+    assert v[i + 1] - v[i] >= min_gap, "no clear confidence gap; change the test seeds"
+    return float(0.5 * (v[i] + v[i + 1]))
+
+
+def _armor_threshold(oracle, heads, rects, margin=0.02):
+    """An armor threshold t in [0.4, 0.8] with per-crop 'fragile' flags: a crop is robust when the
+    oracle's surviving armors are the same at t - margin, t and t + margin (f16 score noise is
+    below margin, and any-higher NMS only lets higher scores suppress lower ones, so the device's
+    survivors are sandwiched between those two sets).  Labels of fragile crops are not compared."""
+    def survivors(h, pc, t):
+        return [int(a["label"]) for a in oracle.postprocess(h, 12, 0.65, t, pc)]
+    best_score, best = -1, None
+    for t in np.arange(0.40, 0.80, 0.02):
+        sets = [[survivors(h, pc, t + d) for d in (-margin, 0.0, margin)] for h, (_, pc) in zip(heads, rects)]
+        frag = np.array([not (s[0] == s[1] == s[2]) for s in sets])
+        lab = np.array([len(s[1]) > 0 for s in sets])
+        score = int((lab & ~frag).sum()) * 100 + int((~frag).sum())  # robust labelled crops first
+        if score > best_score:
+            best_score, best = score, (float(t), frag)
+    return best
+
+
+def _oracle_armor_stage(oracle, armor_heads, rects, car_dets, armor_conf, iou_thresh=0.75):
+    """The armor half of RobotDetector::detect (detector.cpp:430-455) from cached oracle heads."""
     robots = []
-    for c in cars:
-        rect = oracle.crop_rect(tuple(c))
-        if rect[2] <= 0 or rect[3] <= 0:
-            robots.append(oracle.make_robot(tuple(c), np.zeros(0, oracle.DET_DTYPE)))
-            continue
-        b, pc = oracle.preprocess(img, crop=rect)
-        armors = oracle.postprocess(armor32.forward(b[None])[0], 12, 0.65, 0.5, pc)
-        robots.append(oracle.make_robot(tuple(c), armors))
-    return oracle.group_robots(robots, iou_thresh), cars
+    for head, (rect, pc), c in zip(armor_heads, rects, car_dets):
+        armors = oracle.postprocess(head, 12, 0.65, armor_conf, pc)
+        robots.append(oracle.make_robot(c, armors))
+    return oracle.group_robots(robots, iou_thresh)
 
 
 def test_robot_detector_matches_oracle(rmr, oracle, packs, refs, images):
-    rd = rmr.RobotDetector(packs[0], packs[1], (2592, 2048), 12, max_cars=6, opt_cars=4)
+    """RobotDetector::detect (detector.cpp:413-455).  The two confidence thresholds are placed in
+    clear gaps of the oracle's scores and the armor stage is compared on IDENTICAL crops (the
+    oracle's car rects, forced), because a 0.1 px f16 difference in a car box can move the
+    reference's integer crop by a whole pixel and a 1e-2 score difference can move an armor across
+    a threshold -- neither is a property of the code under test."""
+    car32, armor32 = refs["car"][0], refs["armor"][0]
     img = images[0]
-    got = rd.detect(img)
-    want, cars = _oracle_robot_detect(oracle, refs, img, 6)
-    assert len(cars) >= 1
-    # compare as sets keyed by (label, rect): same count of detected / undetected robots,
-    # car rect IoU >= 0.99, identical labels
+    blob, p = oracle.preprocess(img)
+    car_head = car32.forward(blob[None])[0]
+    car_conf = _clear_threshold([car_head], 0.2, 0.6)
+    cars = oracle.postprocess(car_head, 1, 0.65, car_conf, p)[:6]
+    assert len(cars) >= 2
+    rects, armor_heads = [], []
+    for c in cars:
+        rect = oracle.crop_rect(tuple(c))
+        assert rect[2] > 0 and rect[3] > 0
+        b, pc = oracle.preprocess(img, crop=rect)
+        rects.append((rect, pc))
+        armor_heads.append(armor32.forward(b[None])[0])
+    armor_conf, fragile = _armor_threshold(oracle, armor_heads, rects)
+    rd = rmr.RobotDetector(packs[0], packs[1], (2592, 2048), 12, max_cars=6, opt_cars=4,
+                           car_conf_thresh=car_conf, armor_conf_thresh=armor_conf)
+
     def key(r):
-        return (-1 if r.label is None else r.label)
-    gl = sorted(got, key=lambda r: (key(r), r.rect))
-    assert len(got) == len(want)
-    for w in want:
-        wl = w.label if w.has_label else -1
-        ok = any(key(g) == wl and netutil.iou_xywh(g.rect, tuple(w.rect)) >= 0.99 for g in gl)
-        assert ok, f"robot label {wl} rect {tuple(w.rect)} has no partner in {[(key(g), g.rect) for g in gl]}"
-    # batch path == single path
+        return -1 if r.label is None else r.label
+
+    # armor stage on the oracle's crops: same robots, labels and rects
+    forced = [[r for r, _ in rects]]
+    forced_dets = [(float(r[0]), float(r[1]), float(r[2]), float(r[3]), 0.0, 1.0) for r, _ in rects]
+    want = _oracle_armor_stage(oracle, armor_heads, rects, forced_dets, armor_conf)
+    got = rd.detect_batch([img], forced_crops=forced)[0]
+    # preconditions of the comparison (properties of the seeded inputs, not of the device code)
+    assert not fragile.any() and any(w.has_label for w in want), \
+        f"threshold-adjacent armors (car {car_conf:.3f} armor {armor_conf:.3f} fragile {list(fragile)}); change the test seeds"
+    assert sorted((key(g), g.rect) for g in got) == \
+        sorted(((w.label if w.has_label else -1), tuple(float(v) for v in w.rect)) for w in want)
+
+    # whole path: a 0.1 px difference in a car box can move the integer crop by a pixel and with it
+    # an armor label and the grouping, so against the oracle only the car boxes are compared here
+    # (IoU >= 0.99 with one of the oracle's cars); the label logic is covered above on equal crops
+    full = rd.detect(img)
+    assert 1 <= len(full) <= len(cars)
+    for g in full:
+        assert any(netutil.iou_xywh(g.rect, tuple(c)[:4]) >= 0.99 for c in cars), \
+            f"robot rect {g.rect} is not one of the oracle's cars {[tuple(c)[:4] for c in cars]}"
+    # batch path == single path (same kernels, deterministic)
     gb = rd.detect_batch([img])
-    assert [(r.label, r.rect) for r in gb[0]] == [(r.label, r.rect) for r in got]
+    assert [(r.label, r.rect) for r in gb[0]] == [(r.label, r.rect) for r in full]
     # forced crops: robots carry the injected rects
     fc = [[(10, 20, 200, 150), (300, 300, 100, 120)]]
     gf = rd.detect_batch([img], forced_crops=fc)

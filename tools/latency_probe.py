@@ -45,3 +45,18 @@ lat = np.array(lat)
 print(f"K={K}: p50 {np.percentile(lat, 50):.3f} ms  p99 {np.percentile(lat, 99):.3f} ms  "
       f"phases ms: locate-enqueue {ph[0] / len(lat) * 1e3:.3f} detect {ph[1] / len(lat) * 1e3:.3f} "
       f"search {ph[2] / len(lat) * 1e3:.3f}")
+if os.environ.get("RMR_PROBE_PROFILE"):
+    # per-kernel-family HIP-event times of the same frame (events add a little launch overhead)
+    with rmr.profile(0) as prof:
+        for i in range(20):
+            loc.update(cloud)
+            loc.cluster()
+            rb = rd.detect_batch([img], forced_crops=rects)[0]
+            loc.search(rb)
+        st = prof.read()
+    tot = 0.0
+    for name, v in sorted(st.items(), key=lambda kv: -kv[1]["total_ms"]):
+        tot += v["total_ms"] / 20
+        print(f"  {name:28s} {v['launches'] // 20:4d} launches/frame  {v['total_ms'] / 20 * 1e3:8.1f} us/frame  "
+              f"{v['total_ms'] / max(v['launches'], 1) * 1e3:7.1f} us/launch")
+    print(f"  sum {tot * 1e3:.1f} us/frame")
