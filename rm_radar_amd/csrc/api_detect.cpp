@@ -175,7 +175,7 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             RMR_HIP(hipMemsetAsync(dtiming.p, 0, 64, ctx.stream));
             a.timing = dtiming.p;
         }
-        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..: conv_halo tile
+        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..: conv_direct tile
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
         } else if (tile >= 1000) {
@@ -194,6 +194,14 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             launch_conv_dma(ctx, ctx.stream, a, t);
             launch_conv_dma(ctx, ctx.stream, a, t);  // twice: the counters must re-arm themselves
             RMR_HIP(hipStreamSynchronize(ctx.stream));
+        } else if (tile >= 400) {
+            if (!conv_direct_supported(a, tile - 400))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: direct tile %d cannot run this layer", tile - 400);
+            launch_conv_direct(ctx, ctx.stream, a, tile - 400);
+        } else if (tile >= 300) {
+            if (!conv_ws_supported(a, tile - 300))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: weights-stationary variant %d cannot run this layer", tile - 300);
+            launch_conv_ws(ctx, ctx.stream, a, tile - 300);
         } else if (tile >= 200) {
             const int t = tile - 200;
             if (t >= conv_halo_num_tiles() || !conv_halo_supported(a, t))

@@ -61,6 +61,17 @@ int conv_halo_num_tiles();
 ConvTile conv_halo_tile(int id);
 bool conv_halo_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_halo(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+// weights-stationary 3x3 / stride-1 variant for the 48-channel, 160-wide layers (conv_ws.hip): the
+// filter stays in registers and each workgroup walks a strip of image rows
+int conv_ws_num_variants();
+bool conv_ws_supported(const ConvArgs& a, int variant);  // variant < 0: any
+void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant);
+// small-batch variant (conv_direct.hip): operands fetched from L2 in MFMA fragment shape, the K loop
+// split across the waves of a workgroup; Cin % 32 == 0
+int conv_direct_num_tiles();
+ConvTile conv_direct_tile(int id);
+bool conv_direct_supported(const ConvArgs& a, int tile);  // tile < 0: any
+void launch_conv_direct(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
 // picks the kernel family and tile for a layer (RMR_CONV=igemm|dma overrides) and launches it
 void launch_conv_auto(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a);
 

@@ -50,6 +50,7 @@ class Yolov8 {
     // network output: f32 [batch][4+nc][anchors], the tensor TensorRT hands to postprocess
     float* output() { return output_.p; }
     void forward(hipStream_t s, int batch);
+    ~Yolov8();
 
    private:
     enum OpKind { OP_CONV, OP_SPPF, OP_UP, OP_HEAD };
@@ -101,6 +102,15 @@ class Yolov8 {
     DevBuf<float> splitk_ws_;
     DevBuf<int> splitk_cnt_;
     void launch_choice(hipStream_t s, ConvArgs a, int choice);
+    // Small batches are launch-bound (170 kernels of a few microseconds): once every layer of a
+    // batch size is tuned, its forward pass is captured into a hipGraph and replayed.
+    struct Graph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::map<int, Graph> graphs_;
+    int graph_max_batch_ = 8;
+    bool all_tuned(int n) const;
     std::string tune_path_;  // '<pack>.tune': choices persist like the reference's engine cache
     void load_tuning();
     void save_tuning();

@@ -207,6 +207,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     int chunk = 64;
     if (const char* e = std::getenv("RMR_CHUNK")) chunk = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RMR_AUTOTUNE")) autotune_ = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RMR_GRAPH")) graph_max_batch_ = atoi(e);
     chunk_ = std::min(chunk, max_batch);
 
     int ch[5];
@@ -329,7 +330,11 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
 // (layer, batch) -- the analogue of the reference's TensorRT engine build (detector.cpp:177-243).
 void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     const int split = choice / 1000, c = choice % 1000;
-    if (c >= 200) {
+    if (c >= 400) {
+        launch_conv_direct(ctx_, s, a, c - 400);
+    } else if (c >= 300) {
+        launch_conv_ws(ctx_, s, a, c - 300);
+    } else if (c >= 200) {
         launch_conv_halo(ctx_, s, a, c - 200);
     } else if (c >= 100) {
         if (split > 1) {
@@ -353,6 +358,13 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (conv_halo_supported(a, -1))
         for (int t = 0; t < conv_halo_num_tiles(); ++t)
             if (conv_halo_supported(a, t)) cands.push_back(200 + t);
+    // fragment-direct tiles only where the staged kernels cannot fill the chip
+    if (conv_direct_supported(a, -1) && a.M <= 64 * ctx_.num_cus)
+        for (int t = 0; t < conv_direct_num_tiles(); ++t)
+            if (conv_direct_supported(a, t)) cands.push_back(400 + t);
+    if (conv_ws_supported(a, -1))
+        for (int v = 0; v < conv_ws_num_variants(); ++v)
+            if (conv_ws_supported(a, v)) cands.push_back(300 + v);
     // split-K variants where the plain grid cannot fill the chip (small batches)
     if (conv_dma_supported(a))
         for (int t = 0; t < conv_dma_num_tiles(); ++t) {
@@ -374,12 +386,16 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     ctx_.prof.on = false;
     int best = cands.front();
     float best_ms = 1e30f;
+    static const bool verbose = std::getenv("RMR_TUNE_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "tune M%d N%d K%d k%d s%d:", a.M, a.Cout_pad, a.K, a.KH, a.stride);
     for (int c : cands) {
         // skip tiles that would leave most of the chip idle or are hopelessly oversized
         const int cc = c % 1000;
-        const ConvTile t = cc >= 200 ? conv_halo_tile(cc - 200) : cc >= 100 ? conv_dma_tile(cc - 100) : conv_tile(cc);
-        const long blocks = (long)((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
-        if (t.bm >= 256 && blocks < ctx_.num_cus / 2 && a.M > 64) continue;
+        if (cc < 300) {
+            const ConvTile t = cc >= 200 ? conv_halo_tile(cc - 200) : cc >= 100 ? conv_dma_tile(cc - 100) : conv_tile(cc);
+            const long blocks = (long)((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+            if (t.bm >= 256 && blocks < ctx_.num_cus / 2 && a.M > 64) continue;
+        }
         float ms_min = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
             RMR_HIP(hipEventRecord(e0, s));
@@ -390,8 +406,10 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
             RMR_HIP(hipEventElapsedTime(&ms, e0, e1));
             if (rep > 0 && ms < ms_min) ms_min = ms;
         }
+        if (verbose) fprintf(stderr, " %d:%.1f", c, ms_min * 1e3f);
         if (ms_min < best_ms) best_ms = ms_min, best = c;
     }
+    if (verbose) fprintf(stderr, "  -> %d (%.1f us)\n", best, best_ms * 1e3f);
     ctx_.prof.on = prof_was_on;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -406,13 +424,15 @@ void Yolov8::load_tuning() {
     std::string tag;
     int version = 0, n_ops = 0, w = 0, h = 0;
     f >> tag >> version >> n_ops >> w >> h;
-    if (tag != "rmr-tune" || version != 3 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_) return;
+    if (tag != "rmr-tune" || version != 5 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_) return;
     int op, n, choice;
     while (f >> op >> n >> choice) {
         if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV) continue;
         const int c = choice % 1000, split = choice / 1000;
         const bool ok = choice >= 0 && split <= 64 && (split == 0 || (c >= 100 && c < 200)) &&
-                        (c >= 200 ? c - 200 < conv_halo_num_tiles()
+                        (c >= 400 ? c - 400 < conv_direct_num_tiles()
+                         : c >= 300 ? c - 300 < conv_ws_num_variants()
+                         : c >= 200 ? c - 200 < conv_halo_num_tiles()
                                   : c >= 100 ? c - 100 < conv_dma_num_tiles() : c < conv_num_tiles());
         if (ok) tuned_[{op, n}] = choice;
     }
@@ -421,7 +441,7 @@ void Yolov8::load_tuning() {
 void Yolov8::save_tuning() {
     std::ofstream f(tune_path_, std::ios::trunc);
     if (!f) return;  // read-only location: tune again next time
-    f << "rmr-tune 3 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << "\n";
+    f << "rmr-tune 5 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << "\n";
     for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
 }
 
@@ -494,8 +514,42 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
     }
 }
 
+Yolov8::~Yolov8() {
+    for (auto& kv : graphs_) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+}
+
+bool Yolov8::all_tuned(int n) const {
+    for (int i = 0; i < (int)ops_.size(); ++i)
+        if (ops_[i].kind == OP_CONV && autotune_ && !tuned_.count({i, n})) return false;
+    return true;
+}
+
 void Yolov8::forward(hipStream_t s, int batch) {
     if (batch < 0 || batch > max_batch_) fail(RMR_ERR_CAPACITY, "forward: batch %d exceeds max_batch_size %d", batch, max_batch_);
+    // graph replay: one chunk, every layer tuned (tuning synchronises), no per-kernel events
+    if (batch > 0 && batch <= graph_max_batch_ && batch <= chunk_ && !ctx_.prof.on && all_tuned(batch)) {
+        auto it = graphs_.find(batch);
+        if (it == graphs_.end()) {
+            Graph g;
+            RMR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            try {
+                for (int i = 0; i < (int)ops_.size(); ++i) run_op(s, i, batch, 0);
+            } catch (...) {
+                hipGraph_t dead = nullptr;
+                (void)hipStreamEndCapture(s, &dead);
+                if (dead) (void)hipGraphDestroy(dead);
+                throw;
+            }
+            RMR_HIP(hipStreamEndCapture(s, &g.graph));
+            RMR_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+            it = graphs_.emplace(batch, g).first;
+        }
+        RMR_HIP(hipGraphLaunch(it->second.exec, s));
+        return;
+    }
     for (int c0 = 0; c0 < batch; c0 += chunk_) {
         const int n = std::min(chunk_, batch - c0);
         for (int i = 0; i < (int)ops_.size(); ++i) run_op(s, i, n, (size_t)c0);

@@ -134,6 +134,48 @@ def test_conv_halo_every_tile(rmr):
                    False, tile=201)  # 1x1
 
 
+def test_conv_weights_stationary(rmr):
+    # conv_ws.hip (ids 300..): 3x3 / s1, 48 -> 48 channels on 160-wide maps; the filter stays in
+    # registers and a workgroup walks a strip of rows through an LDS ring.  Variants = strip heights.
+    for v, rows in enumerate([40, 20, 10, 8, 4, 2]):
+        run_case(rmr, 2, 40, 160, 48, 48, 3, 1, True, True, tile=300 + v, seed=80 + v)   # 2 images, H = 40
+    run_case(rmr, 1, 160, 160, 48, 48, 3, 1, True, False, tile=300, seed=90)   # 4 strips of 40 rows, no residual
+    run_case(rmr, 3, 6, 160, 48, 48, 3, 1, False, True, tile=305, seed=91)     # strips of 2 rows, H = 6: ring wraps at image ends
+    run_case(rmr, 1, 10, 160, 48, 48, 3, 1, True, True, tile=302, seed=92)     # one strip = whole image
+    run_case(rmr, 1, 20, 160, 48, 41, 3, 1, True, True, tile=301, seed=93)     # 41 channels padded to 48
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 80, 48), np.float32), np.zeros((48, 48, 3, 3), np.float32), None, 1, 1,
+                   False, tile=300)  # W != 160
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 160, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
+                   False, tile=300)  # 96 output channels
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 6, 160, 48), np.float32), np.zeros((48, 48, 3, 3), np.float32), None, 1, 1,
+                   False, tile=300)  # H = 6 is not a multiple of the 40-row strip
+
+
+def test_conv_direct_every_tile(rmr):
+    # conv_direct.hip (ids 400..): fragments straight from L2, K split across the waves of a
+    # workgroup, partial tiles reduced in LDS in wave order.  Every tile on 3x3 (borders, ragged M,
+    # several images), stride 2, 1x1, and K-step counts below / not divisible by the wave count.
+    tiles = [(64, 96, 4), (32, 96, 8), (64, 48, 8), (32, 48, 8), (16, 96, 8), (16, 48, 8), (32, 96, 4),
+             (64, 64, 4), (32, 64, 8), (16, 64, 8), (64, 48, 4), (16, 16, 8)]
+    for t, (bm, bn, nw) in enumerate(tiles):
+        run_case(rmr, 2, 13, 11, 64, bn * 2, 3, 1, True, True, tile=400 + t, seed=100 + t)    # 18 K steps, ragged M
+        run_case(rmr, 1, 9, 9, 32, bn, 1, 1, True, False, tile=400 + t, seed=120 + t)         # 1x1, ONE K step: idle waves
+    run_case(rmr, 4, 40, 40, 192, 192, 3, 1, True, True, tile=400, seed=140)    # the batch-4 P4 bottleneck
+    run_case(rmr, 1, 20, 20, 288, 288, 3, 1, True, True, tile=401, seed=141)    # 81 K steps over 8 waves
+    run_case(rmr, 1, 41, 37, 96, 192, 3, 2, True, False, tile=406, seed=142)    # stride 2, odd sizes
+    run_case(rmr, 1, 20, 20, 576, 16, 1, 1, False, False, tile=411, seed=143)   # 16-channel head conv, no activation
+    run_case(rmr, 3, 8, 8, 160, 64, 3, 1, False, True, tile=407, seed=144)      # 5 chunks per tap
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 8, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
+                   False, tile=400)  # Cin % 32 != 0
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 8, 32), np.float32), np.zeros((48, 32, 3, 3), np.float32), None, 1, 1,
+                   False, tile=400)  # 48 output channels on a 96-wide tile
+
+
 def test_conv_matches_c_oracle(rmr, oracle):
     # the plain-C direct convolution (oracle/rmr_oracle.c) agrees with both
     rng = np.random.default_rng(5)
