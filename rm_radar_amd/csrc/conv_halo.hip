@@ -20,6 +20,11 @@
 //     the next chunk's input range is fetched in 8 portions alongside taps 0..7 of the current
 //     one, so every slice issues the same number of DMA instructions (constant vmcnt immediates).
 //
+//   * TPS (taps per slice) = 1, 3 or 9 sets how much weight data one barrier-to-barrier slice
+//     carries: a slice is TPS taps of one 32-channel chunk.  At TPS = 9 (narrow tiles, BN <= 96)
+//     a 192-channel layer runs 6 slices instead of 54: that is what small batches need, where a
+//     tile's K loop is a serial chain of per-slice costs and one workgroup per CU cannot hide it.
+//
 // Staged bytes per K slice at 256 x 192: 16 KiB instead of 28 KiB (im2col), and the A part no
 // longer grows with the tile height.
 #include <cstdlib>
@@ -37,7 +42,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BSTAGES = 3;       // weight-slice ring
 
 __device__ __forceinline__ float silu_h(float v) { return v / (1.0f + __expf(-v)); }
 
@@ -57,15 +61,19 @@ __device__ __forceinline__ void wait_vm() {
 __device__ __forceinline__ int hkey(int row) { return ((row >> 2) & 1) << 1; }
 
 // A_SLOTS: input-range DMA instructions per slice (taps 0..7 carry them) => up to A_SLOTS*128 rows
-template <int WM, int WN, int MREP, int NREP, int A_SLOTS>
+template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int TPS>
 __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a, const int a_rows) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 16;
     constexpr int BN = WN * NREP * 16;
-    constexpr int NB = BN / 16;                        // weight DMA instructions per slice
-    constexpr int SLOTS = A_SLOTS + NB;                // DMA instructions per slice (workgroup)
+    constexpr int NB = BN / 16;                        // weight DMA instructions per tap
+    constexpr int SPC = 9 / TPS;                       // slices per 32-channel chunk
+    constexpr int BSTAGES = TPS == 9 ? 2 : 3;          // weight-slice ring
+    constexpr int SLOTS = A_SLOTS + NB * TPS;          // DMA instructions per slice (workgroup)
     constexpr int NI = (SLOTS + NW - 1) / NW;          // per wave
-    constexpr int B_STAGE_BYTES = BN * 64;
+    constexpr int B_TAP_BYTES = BN * 64;
+    constexpr int B_STAGE_BYTES = B_TAP_BYTES * TPS;
+    static_assert(TPS == 1 || TPS == 3 || TPS == 9, "a slice is 1, 3 or 9 taps");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert((BSTAGES - 1) * NI <= 63, "vmcnt is 6 bits");
 
@@ -102,13 +110,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     const int lrow = lane >> 2;                       // row inside a 16-row DMA block
     const int lchunk = (lane & 3) ^ hkey(lrow);       // logical 16-byte chunk this lane fetches
     const int na = a_rows / 16;                       // input-range DMA instructions per chunk
-    // weight rows of this lane's B slots (slot q = wave + NW*j; q >= A_SLOTS are weights)
+    // weight rows of this lane's B slots (slot q = wave + NW*j; q >= A_SLOTS are weights: instruction
+    // wi = q - A_SLOTS covers rows 16 (wi % NB) .. +15 of tap wi / NB of the slice)
     int w_off[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int q = wave + NW * j;
-        const int row = (q - A_SLOTS) * 16 + lrow;
-        w_off[j] = (q >= A_SLOTS && q < SLOTS) ? ((n0 + row) * a.Kp + lchunk * 8) * 2 : 0;
+        const int wi = q - A_SLOTS;
+        const int row = (wi % NB) * 16 + lrow;
+        w_off[j] = (q >= A_SLOTS && q < SLOTS) ? ((n0 + row) * a.Kp + (wi / NB) * a.Cin + lchunk * 8) * 2 : 0;
     }
     const int chunks = (a.Cin + 31) / 32;  // the last chunk may be partial (Cin % 32 != 0): the
     // missing channels are zero-filled on BOTH operands (a weight slice must not run into the next tap)
@@ -116,34 +126,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
 
     const unsigned scratch = sgpr(lds0 + b_base + BSTAGES * B_STAGE_BYTES);  // idle slots land here
 
-    // Issues the DMA instructions that ride on slice (cc, t): the weights of the slice
-    // BSTAGES - 1 ahead and, for taps 0..7, one eighth of the NEXT chunk's input range.
-    // t % 3 is a compile-time constant at every call site (the kw loop is unrolled).
-    auto issue = [&](int cc, int t) {
-        const int ahead = t + BSTAGES - 1;
-        const int ks_c = ahead >= 9 ? cc + 1 : cc, ks_t = ahead >= 9 ? ahead - 9 : ahead;  // slice being fetched
+    // Issues the DMA instructions that ride on slice sl = cc * SPC + g: the weights of the slice
+    // BSTAGES - 1 ahead and one SPC-th of the NEXT chunk's input range.
+    auto issue = [&](int cc, int g) {
+        const int f = cc * SPC + g + BSTAGES - 1;            // slice being fetched
+        const int ks_c = f / SPC, ks_g = f - ks_c * SPC;
         const bool w_live = ks_c < chunks;
-        const int wdelta = (ks_t * a.Cin + ks_c * 32) * 2;
-        const int w_stage = ahead % BSTAGES;                // == (9 * ks_c + ks_t) % 3; constant per kw
-        const bool a_live = t < 8 && cc + 1 < chunks;
+        const int wdelta = (ks_g * TPS * a.Cin + ks_c * 32) * 2;
+        const int w_stage = f % BSTAGES;
+        const bool a_live = cc + 1 < chunks;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int q = wave + NW * j;  // wave-uniform slot
             if (q < A_SLOTS) {
-                const int ia = t * A_SLOTS + q;     // DMA block within the input range
+                const int ia = g * A_SLOTS + q;     // DMA block within the input range
                 const int p = lo + ia * 16 + lrow;  // input pixel of this lane's row
                 if (a_live && ia < na) {
                     unsigned off = OOB;
                     if (p >= 0 && p < npix && (cc + 1) * 32 + ch_in_chunk < a.Cin)
                         off = (unsigned)((p * a.in_cs + a.in_co + (cc + 1) * 32 + lchunk * 8) * 2);
                     dma16h(in_rsrc, sgpr(lds0 + ((cc + 1) & 1) * a_buf_bytes + ia * 1024), off);
-                } else {
-                    dma16h(in_rsrc, scratch, OOB);
+                } else if (BSTAGES > 2) {
+                    dma16h(in_rsrc, scratch, OOB);  // keeps the counted vmcnt immediates constant
                 }
             } else if (q < SLOTS) {
                 const unsigned off = (w_live && ks_c * 32 + ch_in_chunk < a.Cin) ? (unsigned)(w_off[j] + wdelta) : OOB;
-                dma16h(wt_rsrc, sgpr(lds0 + b_base + w_stage * B_STAGE_BYTES + (q - A_SLOTS) * 1024), off);
-            } else {
+                if (BSTAGES > 2 || w_live)  // a 2-deep ring drains to vmcnt(0): nothing to keep constant
+                    dma16h(wt_rsrc, sgpr(lds0 + b_base + w_stage * B_STAGE_BYTES + (q - A_SLOTS) * 1024), off);
+            } else if (BSTAGES > 2) {
                 dma16h(wt_rsrc, scratch, OOB);
             }
         }
@@ -162,15 +172,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
         if (p >= 0 && p < npix && ch_in_chunk < a.Cin) off = (unsigned)((p * a.in_cs + a.in_co + lchunk * 8) * 2);
         dma16h(in_rsrc, sgpr(lds0 + ia * 1024), off);
     }
-    // weight slices 0 .. BSTAGES-2 (taps 0, 1 of chunk 0)
+    // weight slices 0 .. BSTAGES-2
 #pragma unroll
     for (int s = 0; s < BSTAGES - 1; ++s) {
+        const int s_c = s / SPC, s_g = s % SPC;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int q = wave + NW * j;
             if (q >= A_SLOTS && q < SLOTS)
                 dma16h(wt_rsrc, sgpr(lds0 + b_base + s * B_STAGE_BYTES + (q - A_SLOTS) * 1024),
-                       ch_in_chunk < a.Cin ? (unsigned)(w_off[j] + s * a.Cin * 2) : OOB);
+                       (s_c < chunks && s_c * 32 + ch_in_chunk < a.Cin) ? (unsigned)(w_off[j] + (s_g * TPS * a.Cin + s_c * 32) * 2) : OOB);
         }
     }
     wait_vm<0>();
@@ -199,18 +210,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     }
     const int b_frag = b_base + (wn * NREP * 16 + frow) * 64 + ((kg ^ hkey(frow)) * 16);
 
+    int sl = 0;              // slices started so far
+    int stage_off = 0;       // ring slot of the slice being computed
     for (int cc = 0; cc < chunks; ++cc) {
         const int a_buf = (cc & 1) * a_buf_bytes;
 #pragma unroll 1
         for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const int t = kh * 3 + kw;  // t % BSTAGES == kw: the ring slot is a compile-time constant
-            wait_vm<(BSTAGES - 2) * NI>();
-            __builtin_amdgcn_s_barrier();
-            issue(cc, t);
+            const int t = kh * 3 + kw;
+            if (TPS == 1 || (TPS == 3 && kw == 0) || (TPS == 9 && t == 0)) {  // head of a slice
+                wait_vm<(BSTAGES - 2) * NI>();
+                __builtin_amdgcn_s_barrier();
+                issue(cc, t / TPS);
+                stage_off = (sl % BSTAGES) * B_STAGE_BYTES;
+                ++sl;
+            }
             const int shift = (kh - 1) * W + (kw - 1);
-            const unsigned char* bp = smem + b_frag + kw * B_STAGE_BYTES;
+            const unsigned char* bp = smem + b_frag + stage_off + (t % TPS) * B_TAP_BYTES;
             half8 xf[MREP], wf[NREP];
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
@@ -273,14 +290,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
 }
 
 struct HaloTile {
-    int bm, bn, threads, max_rows;
+    int bm, bn, threads, max_rows, tps;
     void (*kernel)(const ConvArgs, int);
 };
 
-#define HTILE(WM, WN, MR, NR) \
-    { WM * MR * 16, WN * NR * 16, WM * WN * 64, 4 * 128, conv_halo_kernel<WM, WN, MR, NR, 4> }
-#define HTILE_WIDE(WM, WN, MR, NR) \
-    { WM * MR * 16, WN * NR * 16, WM * WN * 64, 6 * 128, conv_halo_kernel<WM, WN, MR, NR, 6> }
+// A_SLOTS input-range DMA instructions ride on each of the 9 / TPS slices of a chunk
+#define HTILE_T(WM, WN, MR, NR, AS, TPS) \
+    { WM * MR * 16, WN * NR * 16, WM * WN * 64, AS * (9 / TPS) * 16, TPS, conv_halo_kernel<WM, WN, MR, NR, AS, TPS> }
+#define HTILE(WM, WN, MR, NR) HTILE_T(WM, WN, MR, NR, 4, 1)
+#define HTILE_WIDE(WM, WN, MR, NR) HTILE_T(WM, WN, MR, NR, 6, 1)
 
 const HaloTile kHaloTiles[] = {
     HTILE(4, 2, 4, 6),  // 0: 256 x 192
@@ -299,12 +317,28 @@ const HaloTile kHaloTiles[] = {
     HTILE_WIDE(8, 1, 2, 3),  // 12: 256 x 48 (8 waves)
     HTILE_WIDE(4, 2, 4, 3),  // 13: 256 x 96 (8 waves)
     HTILE_WIDE(8, 1, 3, 3),  // 14: 384 x 48 (8 waves)
+    // whole-chunk slices (TPS = 9): narrow tiles for small batches, one barrier per 32 channels
+    HTILE_T(4, 1, 1, 3, 24, 9),  // 15:  64 x 48
+    HTILE_T(4, 1, 2, 3, 24, 9),  // 16: 128 x 48
+    HTILE_T(4, 1, 4, 3, 28, 9),  // 17: 256 x 48
+    HTILE_T(4, 1, 1, 6, 24, 9),  // 18:  64 x 96
+    HTILE_T(4, 1, 2, 6, 24, 9),  // 19: 128 x 96
+    HTILE_T(4, 1, 1, 2, 24, 9),  // 20:  64 x 32
+    HTILE_T(4, 1, 2, 2, 24, 9),  // 21: 128 x 32
+    HTILE_T(4, 1, 1, 4, 24, 9),  // 22:  64 x 64
+    HTILE_T(4, 1, 2, 4, 24, 9),  // 23: 128 x 64
+    HTILE_T(2, 2, 1, 3, 24, 9),  // 24:  32 x 96
+    // one barrier per filter row (TPS = 3)
+    HTILE_T(4, 2, 2, 6, 6, 3),   // 25: 128 x 192
+    HTILE_T(4, 2, 4, 6, 8, 3),   // 26: 256 x 192
+    HTILE_T(4, 2, 4, 3, 10, 3),  // 27: 256 x 96
 };
 constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
 
 int halo_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
 int halo_lds_bytes(const HaloTile& t, int W) {
-    return 2 * halo_rows(t.bm, W) * 64 + BSTAGES * t.bn * 64 + 1024;  // + one scratch KiB for idle slots
+    const int stages = t.tps == 9 ? 2 : 3;
+    return 2 * halo_rows(t.bm, W) * 64 + stages * t.bn * 64 * t.tps + 1024;  // + one scratch KiB for idle slots
 }
 
 }  // namespace

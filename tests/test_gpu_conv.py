@@ -115,7 +115,10 @@ def test_conv_halo_every_tile(rmr):
     # halo-staged 3x3 / stride-1 kernel (conv_halo.hip): tile ids 200..; input range staged once,
     # taps are row shifts, image borders (and image-to-image boundaries inside a tile) are masked
     tiles = [(256, 192), (256, 96), (256, 288), (256, 128), (256, 256), (256, 64), (128, 192), (128, 288),
-             (128, 96), (128, 128), (256, 96), (256, 48), (256, 48), (256, 96), (384, 48)]
+             (128, 96), (128, 128), (256, 96), (256, 48), (256, 48), (256, 96), (384, 48),
+             # whole-chunk slices (9 taps per barrier), then one filter row per barrier
+             (64, 48), (128, 48), (256, 48), (64, 96), (128, 96), (64, 32), (128, 32), (64, 64), (128, 64), (32, 96),
+             (128, 192), (256, 192), (256, 96)]
     for t, (bm, bn) in enumerate(tiles):
         run_case(rmr, 3, 20, 20, 64, bn, 3, 1, True, True, tile=200 + t, seed=t)          # 3 images per ~5 tiles
         run_case(rmr, 1, 19, 23, 32, bn * 2, 3, 1, True, False, tile=200 + t, seed=40 + t)  # odd W, ragged M
@@ -126,6 +129,11 @@ def test_conv_halo_every_tile(rmr):
     run_case(rmr, 1, 160, 160, 48, 48, 3, 1, True, True, tile=211, seed=74)   # Cin 48: partial channel chunk, W = 160
     run_case(rmr, 2, 33, 29, 48, 96, 3, 1, True, False, tile=213, seed=75)    # Cin 48, odd sizes
     run_case(rmr, 1, 24, 24, 40, 48, 3, 1, False, False, tile=212, seed=76)   # Cin 40 (8-channel granularity)
+    run_case(rmr, 4, 40, 40, 192, 192, 3, 1, True, True, tile=216, seed=77)   # batch-4 P4 bottleneck, 6 slices of 9 taps
+    run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, True, tile=219, seed=78)     # W = 80 at 9 taps per slice
+    run_case(rmr, 1, 20, 20, 288, 288, 3, 1, True, True, tile=224, seed=79)   # 32 x 96 tiles, 9 chunks
+    run_case(rmr, 2, 40, 40, 192, 192, 3, 1, True, True, tile=225, seed=80)   # one barrier per filter row
+    run_case(rmr, 1, 33, 29, 48, 96, 3, 1, True, False, tile=218, seed=81)    # Cin 48: partial chunk at 9 taps per slice
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 8, 8, 32), np.float32), np.zeros((96, 32, 3, 3), np.float32), None, 2, 1,
                    False, tile=201)  # stride 2 is not a halo case
