@@ -1,5 +1,6 @@
-// robot.h -- radar::Robot / radar::Label (src/robot/robot.h:32-164) for the detect + locate path.
-// Track-related members (setTrack, track_state, feature) belong to the out-of-scope tracker.
+// robot.h -- radar::Robot / radar::Label / radar::TrackState (src/robot/robot.h:32-164, track.h:26).
+// The track-related state is written by radar::Tracker::update (tracker.h), which applies
+// Robot::setTrack (robot.cpp:81-94) inside the library.
 #pragma once
 #include <optional>
 #include <ostream>
@@ -17,6 +18,8 @@ enum Label {
     BlueSentry = 10, RedSentry = 11
 };
 
+enum class TrackState { Tentative = RMR_TRACK_TENTATIVE, Confirmed = RMR_TRACK_CONFIRMED, Deleted = RMR_TRACK_DELETED };
+
 class Robot {
    public:
     Robot() = default;
@@ -26,6 +29,15 @@ class Robot {
 
     bool isDetected() const noexcept { return armors_.has_value(); }
     bool isLocated() const noexcept { return location_.has_value(); }
+    bool isTracked() const noexcept { return track_state_.has_value(); }
+    std::optional<TrackState> track_state() const noexcept { return track_state_; }
+    // robot.cpp:102-122
+    std::vector<float> feature(int class_num) const {
+        std::vector<float> f((size_t)class_num, 0.f);
+        const rmr_robot c = toC();
+        rmr_robot_feature(&c, class_num, f.data());
+        return f;
+    }
 
     void setDetection(const Detection& car, const std::vector<Detection>& armors) noexcept {
         rmr_robot r{};
@@ -61,17 +73,19 @@ class Robot {
             for (int i = 0; i < r.n_armors; ++i) r.armors[i] = reinterpret_cast<const rmr_detection&>((*armors_)[i]);
         }
         if (location_) r.has_location = 1, r.location[0] = location_->x, r.location[1] = location_->y, r.location[2] = location_->z;
+        r.track_state = track_state_ ? (int)*track_state_ : RMR_TRACK_NONE;
         return r;
     }
     void fromC(const rmr_robot& r) {
         rect_ = Rect2f(r.rect[0], r.rect[1], r.rect[2], r.rect[3]);
-        armors_.reset(), label_.reset(), confidence_.reset(), location_.reset();
-        if (r.has_label) {
-            label_ = r.label;
+        armors_.reset(), label_.reset(), confidence_.reset(), location_.reset(), track_state_.reset();
+        if (r.has_label) label_ = r.label;  // from the armors, or from a track (robot.cpp:81-94)
+        if (r.n_armors > 0) {               // isDetected()
             confidence_ = r.confidence;
             armors_ = std::vector<Detection>(reinterpret_cast<const Detection*>(r.armors),
                                              reinterpret_cast<const Detection*>(r.armors) + r.n_armors);
         }
+        if (r.track_state != RMR_TRACK_NONE) track_state_ = (TrackState)r.track_state;
         if (r.has_location) location_ = Point3f{r.location[0], r.location[1], r.location[2]};
     }
     friend std::ostream& operator<<(std::ostream& os, const Robot& rb) {
@@ -90,6 +104,7 @@ class Robot {
     std::optional<Rect2f> rect_;
     std::optional<int> label_;
     std::optional<float> confidence_;
+    std::optional<TrackState> track_state_;
 };
 
 }  // namespace radar

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RMR_ABI_VERSION 1
+#define RMR_ABI_VERSION 2
 
 typedef int rmr_status;
 enum {
@@ -75,7 +75,14 @@ typedef struct {
     rmr_detection armors[RMR_MAX_ARMORS];
     int has_location;    /* isLocated() */
     float location[3];   /* metres (robot.h:93-95) */
+    int track_state;     /* RMR_TRACK_*: track_state() (robot.h:139-141), set by rmr_tracker_update */
 } rmr_robot;
+
+/* radar::TrackState (track.h:26) with "no track" as the zero value */
+#define RMR_TRACK_NONE 0
+#define RMR_TRACK_TENTATIVE 1
+#define RMR_TRACK_CONFIRMED 2
+#define RMR_TRACK_DELETED 3
 
 /* compact fixed-size record used for the cross-GPU gather of the robot list */
 typedef struct {
@@ -281,6 +288,69 @@ rmr_status rmr_profile_enable(int device, int on);
 rmr_status rmr_profile_reset(int device);
 /* resolves pending events (synchronises), writes up to cap entries, *n = entries available */
 rmr_status rmr_profile_read(int device, rmr_kernel_stat* out, int cap, int* n);
+
+/* ---------------------------------------------------------------- Tracker (host only)
+ * The stage after detect + locate (src/track/): not part of the accelerated path, CPU code as
+ * in the reference.  Matrices are row-major f32. */
+
+/* KalmanFilter<N, M> / ExtendedKalmanFilter<N, M> (kalman_filter.h:77-296).  F, Q, H may be NULL
+ * for an extended filter that receives them per call. */
+typedef struct rmr_kalman rmr_kalman;
+rmr_status rmr_kalman_create(int n, int m, const float* x0, const float* P0, const float* F,
+                             const float* Q, const float* H, const float* R, rmr_kalman** out);
+void rmr_kalman_destroy(rmr_kalman* kf);
+rmr_status rmr_kalman_predict(rmr_kalman* kf);                    /* kalman_filter.h:116-121 */
+rmr_status rmr_kalman_update(rmr_kalman* kf, const float* z);     /* kalman_filter.h:129-152 */
+/* ExtendedKalmanFilter::predict / update with the transition matrix, process noise, predicted
+ * measurement and observation Jacobian already evaluated by the caller (kalman_filter.h:221-248) */
+rmr_status rmr_kalman_predict_ekf(rmr_kalman* kf, const float* F, const float* Q);
+rmr_status rmr_kalman_update_ekf(rmr_kalman* kf, const float* z, const float* hx, const float* H);
+rmr_status rmr_kalman_state(const rmr_kalman* kf, float* x, float* P); /* either may be NULL */
+
+/* SingerEKF (singer.h:33-132): x0[9] = [x vx ax y vy ay z vz az], P0[81], R[9] */
+typedef struct rmr_singer rmr_singer;
+rmr_status rmr_singer_create(const float* x0, const float* P0, float max_a, float tau,
+                             const float* R, rmr_singer** out);
+void rmr_singer_destroy(rmr_singer* s);
+rmr_status rmr_singer_predict(rmr_singer* s, float dt);
+rmr_status rmr_singer_update(rmr_singer* s, const float* z);
+rmr_status rmr_singer_state(const rmr_singer* s, float* x, float* P);
+
+/* auction(value_matrix, max_iter) (auction.h:49-127): values[agents][tasks] -> assignment[agents],
+ * -1 = not matched */
+rmr_status rmr_auction(const float* values, int agents, int tasks, int max_iter, int* assignment);
+/* Robot::feature(class_num) (robot.cpp:102-122) */
+rmr_status rmr_robot_feature(const rmr_robot* r, int class_num, float* out);
+
+/* Tracker::Tracker arguments (tracker.h:25-30) */
+typedef struct {
+    float observation_noise[3];          /* metres */
+    int class_num;
+    int init_thresh;                     /* 4 */
+    int miss_thresh;                     /* 10 */
+    float max_acceleration;              /* 2.0 */
+    float acceleration_correlation_time; /* 1.0 */
+    float distance_weight;               /* 0.40 */
+    float feature_weight;                /* 0.60 */
+    int max_iter;                        /* 100 */
+    float distance_thresh;               /* 0.8 */
+} rmr_tracker_cfg;
+
+typedef struct {
+    int id, state, label, init_count, miss_count;
+    float location[3];
+    float state_vector[9];
+} rmr_track_info;
+
+typedef struct rmr_tracker rmr_tracker;
+void rmr_tracker_cfg_default(rmr_tracker_cfg* cfg);
+rmr_status rmr_tracker_create(const rmr_tracker_cfg* cfg, rmr_tracker** out);
+void rmr_tracker_destroy(rmr_tracker* t);
+/* Tracker::update(robots, timestamp) (tracker.cpp:126-220); timestamp in nanoseconds.  Robots are
+ * updated in place (label, location, track_state) as Robot::setTrack does (robot.cpp:81-94). */
+rmr_status rmr_tracker_update(rmr_tracker* t, rmr_robot* robots, int n, int64_t timestamp_ns);
+/* the live tracks, in the tracker's order (tests / diagnostics) */
+rmr_status rmr_tracker_tracks(const rmr_tracker* t, rmr_track_info* out, int cap, int* n);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ class Robot(C.Structure):
         ("armors", Detection * MAX_ARMORS),
         ("has_location", C.c_int),
         ("location", C.c_float * 3),
+        ("track_state", C.c_int),
     ]
 
 

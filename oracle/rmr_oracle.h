@@ -100,6 +100,7 @@ typedef struct {
     orc_detection armors[ORC_MAX_ARMORS];
     int has_location;
     float location[3];  /* metres (robot.h:93-95) */
+    int track_state;    /* 0 none, 1 tentative, 2 confirmed, 3 deleted (track.h:26) -- set by the tracker stage */
 } orc_robot;
 
 /* robot.cpp:41-74 */

@@ -20,6 +20,7 @@ from ._lib import (CapacityError, DET_DTYPE, DeviceError, InvalidArgument, PrePa
 __all__ = ["Detector", "RobotDetector", "Locator", "Robot", "PreParam", "preparam",
            "letterbox_geometry", "letterbox", "preprocess", "postprocess", "transpose",
            "conv2d", "restore_detection", "device_count", "profile", "DET_DTYPE", "RmrError",
+           "Tracker", "KalmanFilter", "SingerEKF", "auction", "TRACK_TENTATIVE", "TRACK_CONFIRMED", "TRACK_DELETED",
            "InvalidArgument", "DeviceError", "CapacityError", "Label"]
 
 # radar::Label (src/robot/robot.h:32-45)
@@ -164,6 +165,7 @@ class Robot:
     confidence: Optional[float] = None
     armors: Optional[np.ndarray] = None
     location: Optional[tuple] = None
+    track_state: Optional[int] = None  # TRACK_TENTATIVE / TRACK_CONFIRMED once a Tracker has seen it
 
     def is_detected(self) -> bool:
         return self.armors is not None
@@ -171,15 +173,19 @@ class Robot:
     def is_located(self) -> bool:
         return self.location is not None
 
+    def is_tracked(self) -> bool:
+        return self.track_state is not None
+
     @staticmethod
     def from_c(r: _lib.Robot) -> "Robot":
         armors = None
-        if r.has_label:
+        if r.n_armors > 0:  # isDetected(); a label alone can also come from a track (robot.cpp:81-94)
             armors = np.array([(a.x, a.y, a.width, a.height, a.label, a.confidence)
                                for a in r.armors[: r.n_armors]], DET_DTYPE)
         return Robot(rect=tuple(r.rect), label=r.label if r.has_label else None,
-                     confidence=r.confidence if r.has_label else None, armors=armors,
-                     location=tuple(r.location) if r.has_location else None)
+                     confidence=r.confidence if r.n_armors > 0 else None, armors=armors,
+                     location=tuple(r.location) if r.has_location else None,
+                     track_state=r.track_state if r.track_state else None)
 
     def to_c(self) -> _lib.Robot:
         r = _lib.Robot()
@@ -194,7 +200,15 @@ class Robot:
         if self.location is not None:
             r.has_location = 1
             r.location[:] = [float(v) for v in self.location]
+        r.track_state = self.track_state or 0
         return r
+
+    def feature(self, class_num: int) -> np.ndarray:
+        """Robot::feature (robot.cpp:102-122)"""
+        out = np.zeros(class_num, np.float32)
+        c = self.to_c()
+        check(lib().rmr_robot_feature(C.byref(c), class_num, _lib.fp(out)))
+        return out
 
     @staticmethod
     def from_detection(car, armors) -> "Robot":
@@ -479,6 +493,165 @@ class Locator:
 
 
 # ------------------------------------------------------------------------------- profiling
+
+# ------------------------------------------------------------------------------- Tracker (host)
+
+TRACK_TENTATIVE, TRACK_CONFIRMED, TRACK_DELETED = 1, 2, 3
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, np.float32)
+    if shape is not None and a.shape != shape:
+        raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, f"expected an array of shape {shape}, got {a.shape}")
+    return a
+
+
+class KalmanFilter:
+    """radar::track::KalmanFilter / ExtendedKalmanFilter (src/track/kalman_filter.h:77-296).
+    Without F, Q, H it is the extended filter: predict(F, Q) and update(z, hx, H) take the
+    transition, process noise, predicted measurement and Jacobian evaluated by the caller."""
+
+    def __init__(self, x0, P0, R, F=None, Q=None, H=None):
+        x0 = _f32(x0)
+        self.n, self.m = len(x0), len(np.atleast_2d(np.asarray(R)))
+        P0, R = _f32(P0, (self.n, self.n)), _f32(R, (self.m, self.m))
+        model = [None if a is None else _f32(a, sh) for a, sh in
+                 ((F, (self.n, self.n)), (Q, (self.n, self.n)), (H, (self.m, self.n)))]
+        self._h = C.c_void_p()
+        check(lib().rmr_kalman_create(self.n, self.m, _lib.fp(x0), _lib.fp(P0),
+                                      *[None if a is None else _lib.fp(a) for a in model],
+                                      _lib.fp(R), C.byref(self._h)))
+
+    def predict(self, F=None, Q=None):
+        if F is None:
+            check(lib().rmr_kalman_predict(self._h))
+        else:
+            check(lib().rmr_kalman_predict_ekf(self._h, _lib.fp(_f32(F, (self.n, self.n))),
+                                               _lib.fp(_f32(Q, (self.n, self.n)))))
+
+    def update(self, z, hx=None, H=None):
+        z = _f32(z, (self.m,))
+        if hx is None:
+            check(lib().rmr_kalman_update(self._h, _lib.fp(z)))
+        else:
+            check(lib().rmr_kalman_update_ekf(self._h, _lib.fp(z), _lib.fp(_f32(hx, (self.m,))),
+                                              _lib.fp(_f32(H, (self.m, self.n)))))
+
+    @property
+    def state(self):
+        x = np.empty(self.n, np.float32)
+        check(lib().rmr_kalman_state(self._h, _lib.fp(x), None))
+        return x
+
+    @property
+    def covariance(self):
+        P = np.empty((self.n, self.n), np.float32)
+        check(lib().rmr_kalman_state(self._h, None, _lib.fp(P)))
+        return P
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib().rmr_kalman_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class SingerEKF:
+    """radar::track::SingerEKF (src/track/singer.h:33-132): state [x vx ax y vy ay z vz az]."""
+
+    def __init__(self, initial_state, initial_covariance, max_a, tau, observation_noise):
+        self._h = C.c_void_p()
+        check(lib().rmr_singer_create(_lib.fp(_f32(initial_state, (9,))), _lib.fp(_f32(initial_covariance, (9, 9))),
+                                      float(max_a), float(tau), _lib.fp(_f32(observation_noise, (3, 3))),
+                                      C.byref(self._h)))
+
+    def predict(self, dt):
+        check(lib().rmr_singer_predict(self._h, float(dt)))
+
+    def update(self, measurement):
+        check(lib().rmr_singer_update(self._h, _lib.fp(_f32(measurement, (3,)))))
+
+    @property
+    def state(self):
+        x = np.empty(9, np.float32)
+        check(lib().rmr_singer_state(self._h, _lib.fp(x), None))
+        return x
+
+    @property
+    def covariance(self):
+        P = np.empty((9, 9), np.float32)
+        check(lib().rmr_singer_state(self._h, None, _lib.fp(P)))
+        return P
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib().rmr_singer_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def auction(value_matrix, max_iter=100):
+    """radar::track::auction (src/track/auction.h:49-127): rows are agents, columns tasks;
+    returns the task of each agent, -1 where not matched."""
+    v = np.ascontiguousarray(value_matrix, np.float32)
+    if v.ndim != 2:
+        raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "auction: value_matrix must be 2-D")
+    out = np.full(v.shape[0], -1, np.int32)
+    check(lib().rmr_auction(_lib.fp(v), v.shape[0], v.shape[1], int(max_iter), _lib.ip(out)))
+    return out
+
+
+class Tracker:
+    """radar::Tracker (src/track/tracker.h:23-54): Singer-EKF tracks, auction matching on a
+    distance + class-feature score, tentative / confirmed / deleted bookkeeping.  CPU code, as
+    in the reference."""
+
+    def __init__(self, observation_noise, class_num, init_thresh=4, miss_thresh=10, max_acceleration=2.0,
+                 acceleration_correlation_time=1.0, distance_weight=0.40, feature_weight=0.60, max_iter=100,
+                 distance_thresh=0.8):
+        cfg = _lib.TrackerCfg()
+        lib().rmr_tracker_cfg_default(C.byref(cfg))
+        cfg.observation_noise[:] = [float(v) for v in observation_noise]
+        cfg.class_num, cfg.init_thresh, cfg.miss_thresh = class_num, init_thresh, miss_thresh
+        cfg.max_acceleration = max_acceleration
+        cfg.acceleration_correlation_time = acceleration_correlation_time
+        cfg.distance_weight, cfg.feature_weight = distance_weight, feature_weight
+        cfg.max_iter, cfg.distance_thresh = max_iter, distance_thresh
+        self._h = C.c_void_p()
+        check(lib().rmr_tracker_create(C.byref(cfg), C.byref(self._h)))
+
+    def update(self, robots: List[Robot], timestamp) -> List[Robot]:
+        """Tracker::update(robots, timestamp) (tracker.cpp:126-220).  `timestamp`: seconds (float)
+        or nanoseconds (int).  The robots are updated in place and returned."""
+        t_ns = int(timestamp) if isinstance(timestamp, (int, np.integer)) else int(round(float(timestamp) * 1e9))
+        arr = (_lib.Robot * max(len(robots), 1))()
+        for i, r in enumerate(robots):
+            arr[i] = r.to_c()
+        check(lib().rmr_tracker_update(self._h, arr, len(robots), t_ns))
+        for i, r in enumerate(robots):
+            u = Robot.from_c(arr[i])
+            r.label, r.location, r.track_state = u.label, u.location, u.track_state
+        return robots
+
+    def tracks(self):
+        """Live tracks as dicts (id, state, label, init_count, miss_count, location, state_vector)."""
+        n = C.c_int()
+        check(lib().rmr_tracker_tracks(self._h, None, 0, C.byref(n)))
+        arr = (_lib.TrackInfo * max(n.value, 1))()
+        check(lib().rmr_tracker_tracks(self._h, arr, n.value, C.byref(n)))
+        return [dict(id=t.id, state=t.state, label=t.label, init_count=t.init_count, miss_count=t.miss_count,
+                     location=tuple(t.location), state_vector=np.array(t.state_vector[:], np.float32))
+                for t in arr[: n.value]]
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib().rmr_tracker_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
 
 class profile:
     """HIP-event timing of the library's own launches (on the streams they run on)."""

@@ -56,7 +56,7 @@ class Robot(C.Structure):
     _fields_ = [("rect", C.c_float * 4), ("has_label", C.c_int), ("label", C.c_int),
                 ("confidence", C.c_float), ("n_armors", C.c_int),
                 ("armors", Detection * MAX_ARMORS), ("has_location", C.c_int),
-                ("location", C.c_float * 3)]
+                ("location", C.c_float * 3), ("track_state", C.c_int)]
 
 
 class RobotRecord(C.Structure):
@@ -92,6 +92,18 @@ class LocatorCfg(C.Structure):
                 ("min_cluster_size", C.c_int), ("max_cluster_size", C.c_int),
                 ("max_distance", C.c_float), ("device", C.c_int), ("max_points", C.c_int),
                 ("max_foreground", C.c_int), ("max_frames", C.c_int)]
+
+
+class TrackerCfg(C.Structure):
+    _fields_ = [("observation_noise", C.c_float * 3), ("class_num", C.c_int), ("init_thresh", C.c_int),
+                ("miss_thresh", C.c_int), ("max_acceleration", C.c_float),
+                ("acceleration_correlation_time", C.c_float), ("distance_weight", C.c_float),
+                ("feature_weight", C.c_float), ("max_iter", C.c_int), ("distance_thresh", C.c_float)]
+
+
+class TrackInfo(C.Structure):
+    _fields_ = [("id", C.c_int), ("state", C.c_int), ("label", C.c_int), ("init_count", C.c_int),
+                ("miss_count", C.c_int), ("location", C.c_float * 3), ("state_vector", C.c_float * 9)]
 
 
 class KernelStat(C.Structure):
@@ -154,6 +166,26 @@ SYMBOLS = {
     "rmr_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "rmr_profile_reset": (C.c_int, [C.c_int]),
     "rmr_profile_read": (C.c_int, [C.c_int, _P(KernelStat), C.c_int, _ip]),
+    # tracker stage (host only)
+    "rmr_kalman_create": (C.c_int, [C.c_int, C.c_int] + [_fp] * 6 + [_P(C.c_void_p)]),
+    "rmr_kalman_destroy": (None, [C.c_void_p]),
+    "rmr_kalman_predict": (C.c_int, [C.c_void_p]),
+    "rmr_kalman_update": (C.c_int, [C.c_void_p, _fp]),
+    "rmr_kalman_predict_ekf": (C.c_int, [C.c_void_p, _fp, _fp]),
+    "rmr_kalman_update_ekf": (C.c_int, [C.c_void_p, _fp, _fp, _fp]),
+    "rmr_kalman_state": (C.c_int, [C.c_void_p, _fp, _fp]),
+    "rmr_singer_create": (C.c_int, [_fp, _fp, C.c_float, C.c_float, _fp, _P(C.c_void_p)]),
+    "rmr_singer_destroy": (None, [C.c_void_p]),
+    "rmr_singer_predict": (C.c_int, [C.c_void_p, C.c_float]),
+    "rmr_singer_update": (C.c_int, [C.c_void_p, _fp]),
+    "rmr_singer_state": (C.c_int, [C.c_void_p, _fp, _fp]),
+    "rmr_auction": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _ip]),
+    "rmr_robot_feature": (C.c_int, [_P(Robot), C.c_int, _fp]),
+    "rmr_tracker_cfg_default": (None, [_P(TrackerCfg)]),
+    "rmr_tracker_create": (C.c_int, [_P(TrackerCfg), _P(C.c_void_p)]),
+    "rmr_tracker_destroy": (None, [C.c_void_p]),
+    "rmr_tracker_update": (C.c_int, [C.c_void_p, _P(Robot), C.c_int, C.c_int64]),
+    "rmr_tracker_tracks": (C.c_int, [C.c_void_p, _P(TrackInfo), C.c_int, _ip]),
 }
 
 _lib = None

@@ -128,12 +128,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
 
     // Issues the DMA instructions that ride on slice sl = cc * SPC + g: the weights of the slice
     // BSTAGES - 1 ahead and one SPC-th of the NEXT chunk's input range.
-    auto issue = [&](int cc, int g) {
-        const int f = cc * SPC + g + BSTAGES - 1;            // slice being fetched
-        const int ks_c = f / SPC, ks_g = f - ks_c * SPC;
+    // With BSTAGES dividing the slices of a chunk the ring slot of a slice is g % BSTAGES: a
+    // compile-time constant at every call site of the unrolled kw loop when TPS == 1.
+    auto issue = [&](int cc, int g, int kw) {
+        const int ahead = g + BSTAGES - 1;                   // slice being fetched, relative to chunk cc
+        const int ks_c = ahead >= SPC ? cc + 1 : cc, ks_g = ahead >= SPC ? ahead - SPC : ahead;
         const bool w_live = ks_c < chunks;
         const int wdelta = (ks_g * TPS * a.Cin + ks_c * 32) * 2;
-        const int w_stage = f % BSTAGES;
+        const int w_stage = TPS == 9 ? ((cc + 1) & 1) : TPS == 1 ? (kw + BSTAGES - 1) % BSTAGES : ahead % BSTAGES;
         const bool a_live = cc + 1 < chunks;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -210,7 +212,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     }
     const int b_frag = b_base + (wn * NREP * 16 + frow) * 64 + ((kg ^ hkey(frow)) * 16);
 
-    int sl = 0;              // slices started so far
     int stage_off = 0;       // ring slot of the slice being computed
     for (int cc = 0; cc < chunks; ++cc) {
         const int a_buf = (cc & 1) * a_buf_bytes;
@@ -222,9 +223,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
             if (TPS == 1 || (TPS == 3 && kw == 0) || (TPS == 9 && t == 0)) {  // head of a slice
                 wait_vm<(BSTAGES - 2) * NI>();
                 __builtin_amdgcn_s_barrier();
-                issue(cc, t / TPS);
-                stage_off = (sl % BSTAGES) * B_STAGE_BYTES;
-                ++sl;
+                issue(cc, t / TPS, kw);
+                stage_off = (TPS == 9 ? (cc & 1) : TPS == 3 ? kh : kw) * B_STAGE_BYTES;
             }
             const int shift = (kh - 1) * W + (kw - 1);
             const unsigned char* bp = smem + b_frag + stage_off + (t % TPS) * B_TAP_BYTES;

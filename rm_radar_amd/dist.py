@@ -21,7 +21,7 @@ from . import _lib
 ROBOT_DTYPE = np.dtype([("rect", np.float32, 4), ("has_label", np.int32), ("label", np.int32),
                         ("confidence", np.float32), ("n_armors", np.int32),
                         ("armors", np.float32, (_lib.MAX_ARMORS, 6)), ("has_location", np.int32),
-                        ("location", np.float32, 3)])
+                        ("location", np.float32, 3), ("track_state", np.int32)])
 assert ROBOT_DTYPE.itemsize == C.sizeof(_lib.Robot)
 
 # rmr_robot_record as 12 x 4-byte words: rect[4], location[3], confidence, label, flags,

@@ -19,6 +19,21 @@ int main() {
                {Detection(1, 1, 5, 5, 3, 0.6f), Detection(2, 2, 5, 5, 5, 0.5f), Detection(3, 3, 5, 5, 3, 0.3f)});
     if (!vote.isDetected() || vote.label().value() != 3) return std::puts("FAIL vote"), 1;
 
+    // the tracker stage is host code: a robot seen five times becomes a confirmed track
+    // (tracker.h:25-30 defaults: init_thresh 4)
+    {
+        Tracker tracker(Point3f{0.1f, 0.1f, 0.1f}, 12);
+        const auto t0 = std::chrono::high_resolution_clock::time_point{} + std::chrono::seconds(1);
+        std::vector<Robot> seen;
+        for (int i = 0; i < 5; ++i) {
+            seen.assign(1, vote);
+            seen[0].setLocationMetres(Point3f{1.f + 0.01f * i, 2.f, 3.f});
+            tracker.update(seen, t0 + std::chrono::milliseconds(100 * i));
+        }
+        if (!seen[0].isTracked() || *seen[0].track_state() != TrackState::Confirmed) return std::puts("FAIL tracker"), 1;
+        if (seen[0].feature(12)[3] < 0.6f) return std::puts("FAIL feature"), 1;
+    }
+
     try {
         Detector d("/nonexistent/car.rmrw", 1, Size(640, 640), 1);
         return std::puts("FAIL: missing engine accepted"), 1;

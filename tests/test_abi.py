@@ -28,13 +28,13 @@ def test_exports_every_declared_symbol(built):
     assert declared == set(built.SYMBOLS), declared ^ set(built.SYMBOLS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.rmr_abi_version() == 1
+    assert L.rmr_abi_version() == 2
 
 
 def test_struct_layouts(built):
     assert C.sizeof(built.Detection) == 24          # detection.h:62-67: six f32
     assert C.sizeof(built.PreParam) == 20
-    assert C.sizeof(built.Robot) == 16 + 4 * 4 + 64 * 24 + 4 + 12
+    assert C.sizeof(built.Robot) == 16 + 4 * 4 + 64 * 24 + 4 + 12 + 4   # + track_state (ABI 2)
     assert C.sizeof(built.RobotRecord) == 48
     assert built.DET_DTYPE.itemsize == 24
 
