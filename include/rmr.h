@@ -265,6 +265,12 @@ int rmr_locator_width(const rmr_locator* loc);  /* image_width_zoomed_ */
 int rmr_locator_height(const rmr_locator* loc);
 rmr_status rmr_locator_read_image(rmr_locator* loc, int which, float* host_out);
 rmr_status rmr_locator_write_image(rmr_locator* loc, int which, const float* host_in);
+/* Snapshot of the temporal state the reference keeps only in memory (locator.h:90-91: background
+ * image + queue of depth images): lets a stream restart, or move to another GPU, without
+ * re-accumulating its background.  The blob is host memory of rmr_locator_state_bytes bytes. */
+rmr_status rmr_locator_state_bytes(const rmr_locator* loc, size_t* bytes);
+rmr_status rmr_locator_save_state(rmr_locator* loc, void* host_out, size_t cap);
+rmr_status rmr_locator_load_state(rmr_locator* loc, const void* host_in, size_t bytes);
 rmr_status rmr_locator_transform(const rmr_locator* loc, int which, const float in[3], float out[3]);
 rmr_status rmr_locator_zoom(const rmr_locator* loc, const int rect[4], int out[4]);
 /* cluster() products: foreground points in scan order (lidar frame, mm), their pixel

@@ -457,6 +457,28 @@ class Locator:
         assert img.shape == (self.hz, self.wz)
         check(lib().rmr_locator_write_image(self._h, which, _lib.fp(img)))
 
+    def save_state(self, path=None) -> bytes:
+        """Background image + depth-image queue as one blob (optionally written to `path`): the
+        temporal state of locator.h:90-91, which the reference never persists."""
+        n = C.c_size_t()
+        check(lib().rmr_locator_state_bytes(self._h, C.byref(n)))
+        buf = (C.c_char * n.value)()
+        check(lib().rmr_locator_save_state(self._h, buf, n.value))
+        blob = bytes(buf)
+        if path is not None:
+            with open(path, "wb") as f:
+                f.write(blob)
+        return blob
+
+    def load_state(self, blob_or_path) -> None:
+        """Restores what save_state produced (same image size and queue_size required)."""
+        blob = blob_or_path
+        if not isinstance(blob, (bytes, bytearray)):
+            with open(blob_or_path, "rb") as f:
+                blob = f.read()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        check(lib().rmr_locator_load_state(self._h, buf, len(blob)))
+
     def _xf(self, which, p):
         a = np.asarray(p, np.float32)
         o = np.zeros(3, np.float32)

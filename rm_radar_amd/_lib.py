@@ -159,6 +159,9 @@ SYMBOLS = {
     "rmr_locator_height": (C.c_int, [_vp]),
     "rmr_locator_read_image": (C.c_int, [_vp, C.c_int, _fp]),
     "rmr_locator_write_image": (C.c_int, [_vp, C.c_int, _fp]),
+    "rmr_locator_state_bytes": (C.c_int, [_vp, _P(C.c_size_t)]),
+    "rmr_locator_save_state": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "rmr_locator_load_state": (C.c_int, [_vp, _vp, C.c_size_t]),
     "rmr_locator_transform": (C.c_int, [_vp, C.c_int, _fp, _fp]),
     "rmr_locator_zoom": (C.c_int, [_vp, _ip, _ip]),
     "rmr_locator_foreground": (C.c_int, [_vp, _fp, _ip, _ip, C.c_int, _ip]),

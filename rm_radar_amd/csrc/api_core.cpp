@@ -271,6 +271,16 @@ rmr_status rmr_locator_read_image(rmr_locator* loc, int which, float* host_out) 
 rmr_status rmr_locator_write_image(rmr_locator* loc, int which, const float* host_in) {
     LOC_CALL(loc->impl.write_image(which, host_in));
 }
+rmr_status rmr_locator_state_bytes(const rmr_locator* loc, size_t* bytes) {
+    LOC_CALL(if (!bytes) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_locator_state_bytes: null argument");
+             *bytes = loc->impl.state_bytes());
+}
+rmr_status rmr_locator_save_state(rmr_locator* loc, void* host_out, size_t cap) {
+    LOC_CALL(loc->impl.save_state(host_out, cap));
+}
+rmr_status rmr_locator_load_state(rmr_locator* loc, const void* host_in, size_t bytes) {
+    LOC_CALL(loc->impl.load_state(host_in, bytes));
+}
 rmr_status rmr_locator_transform(const rmr_locator* loc, int which, const float in[3], float out[3]) {
     LOC_CALL(loc->impl.transform(which, in, out));
 }

@@ -41,6 +41,11 @@ class Locator {
     int height() const { return prm_.hz; }
     void read_image(int which, float* host_out);
     void write_image(int which, const float* host_in);
+    // temporal state (background + depth ring) as one host blob: a stream can restart, or move to
+    // another GPU, without re-accumulating its background
+    size_t state_bytes() const;
+    void save_state(void* host_out, size_t cap);
+    void load_state(const void* host_in, size_t bytes);
     void transform(int which, const float in[3], float out[3]) const;
     void zoom(const int rect[4], int out[4]) const;
     void foreground(float* xyz, int* pixel, int* cluster, int cap, int* n);

@@ -820,6 +820,53 @@ void Locator::write_image(int which, const float* host_in) {
     RMR_HIP(hipStreamSynchronize(stream_));
 }
 
+// ---- snapshot of the temporal state -------------------------------------------------------------
+// header (8 ints: magic, version, zoomed width, height, queue_size, valid ring slots, 0, 0), the
+// background image, then the valid depth images oldest first.
+namespace {
+constexpr int kStateMagic = 0x4c524d52;  // "RMRL"
+constexpr int kStateVersion = 1;
+}  // namespace
+
+size_t Locator::state_bytes() const { return 8 * sizeof(int) + (size_t)(1 + cfg_.queue_size) * npx_ * sizeof(float); }
+
+void Locator::save_state(void* host_out, size_t cap) {
+    if (!host_out || cap < state_bytes()) fail(RMR_ERR_CAPACITY, "Locator::save_state: buffer of %zu bytes, %zu needed", cap, state_bytes());
+    ctx_.use();
+    int* hdr = (int*)host_out;
+    const int h[8] = {kStateMagic, kStateVersion, prm_.wz, prm_.hz, cfg_.queue_size, ring_len_, 0, 0};
+    std::copy(h, h + 8, hdr);
+    float* img = (float*)(hdr + 8);
+    RMR_HIP(hipMemcpyAsync(img, bg_.p, npx_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    for (int i = 0; i < cfg_.queue_size; ++i) {
+        float* dst = img + (size_t)(1 + i) * npx_;
+        if (i < ring_len_) {
+            const int slot = (ring_head_ + i) % cfg_.queue_size;
+            RMR_HIP(hipMemcpyAsync(dst, ring_.p + (size_t)slot * npx_, npx_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        } else {
+            std::fill(dst, dst + npx_, 0.f);
+        }
+    }
+    RMR_HIP(hipStreamSynchronize(stream_));
+}
+
+void Locator::load_state(const void* host_in, size_t bytes) {
+    if (!host_in || bytes < 8 * sizeof(int)) fail(RMR_ERR_INVALID_ARGUMENT, "Locator::load_state: truncated snapshot");
+    const int* hdr = (const int*)host_in;
+    if (hdr[0] != kStateMagic || hdr[1] != kStateVersion) fail(RMR_ERR_INVALID_ARGUMENT, "Locator::load_state: not a locator snapshot");
+    if (hdr[2] != prm_.wz || hdr[3] != prm_.hz || hdr[4] != cfg_.queue_size)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator::load_state: snapshot is %d x %d with %d depth images, this locator %d x %d with %d",
+             hdr[2], hdr[3], hdr[4], prm_.wz, prm_.hz, cfg_.queue_size);
+    if (bytes < state_bytes() || hdr[5] < 0 || hdr[5] > cfg_.queue_size) fail(RMR_ERR_INVALID_ARGUMENT, "Locator::load_state: truncated snapshot");
+    ctx_.use();
+    const float* img = (const float*)(hdr + 8);
+    RMR_HIP(hipMemcpyAsync(bg_.p, img, npx_ * sizeof(float), hipMemcpyHostToDevice, stream_));
+    RMR_HIP(hipMemcpyAsync(ring_.p, img + npx_, (size_t)cfg_.queue_size * npx_ * sizeof(float), hipMemcpyHostToDevice, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+    ring_head_ = 0;
+    ring_len_ = hdr[5];
+}
+
 void Locator::transform(int which, const float in[3], float out[3]) const {
     switch (which) {
         case RMR_XF_LIDAR_TO_WORLD: lidar_to_world(prm_, in, out); return;

@@ -203,3 +203,48 @@ def test_keep_and_search_kept(rmr, oracle):
             assert (want is None) == (rb.location is None)
             if want is not None:
                 assert np.max(np.abs(np.array(rb.location) - want)) <= XYZ_TOL_M
+
+
+def test_state_snapshot_resumes_a_stream(rmr, oracle, tmp_path):
+    # background image + depth-image queue saved after 7 frames (the queue of 3 has
+    # wrapped) and restored into a NEW locator; both then see the same frames and must agree with
+    # each other and with the uninterrupted CPU oracle bit for bit.
+    size = (640, 640)
+    rng = np.random.default_rng(11)
+    spec = [((100, 300, 120, 90), 2000, 200), ((400, 200, 80, 120), 1500, 150)]
+    gpu, cpu = _pair(rmr, oracle, size, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+    bg = scenes.make_cloud(rng, 30000, scenes.K640, scenes.SAMPLE_L2C, size)  # background pass
+    gpu.update(bg), cpu.update(bg)
+    for i in range(6):
+        c = scenes.make_cloud(rng, 20000, scenes.K640, scenes.SAMPLE_L2C, size, spec if i % 2 else spec[:1])
+        gpu.update(c), cpu.update(c)
+    path = tmp_path / "stream0.rmrl"
+    blob = gpu.save_state(str(path))
+    assert path.stat().st_size == len(blob) == 32 + 4 * 320 * 320 * 4  # header, background, queue_size = 3 depth images
+    resumed = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+    resumed.load_state(str(path))
+    assert np.array_equal(resumed.read_image(resumed.BACKGROUND), cpu.background_image)
+    for i in range(4):
+        c = scenes.make_cloud(rng, 20000, scenes.K640, scenes.SAMPLE_L2C, size, spec if i % 2 == 0 else ())
+        for loc in (gpu, resumed):
+            loc.update(c)
+            loc.cluster()
+        cpu.update(c)
+        for which in (gpu.BACKGROUND, gpu.DEPTH, gpu.DIFF):
+            assert np.array_equal(gpu.read_image(which), resumed.read_image(which))
+        assert np.array_equal(resumed.read_image(resumed.DIFF), cpu.diff_image)
+        a, b = gpu.foreground(), resumed.foreground()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # a half-filled queue round-trips too, and mismatched geometry is refused
+    fresh = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+    fresh.update(scenes.make_cloud(rng, 1000, scenes.K640, scenes.SAMPLE_L2C, size))
+    twin = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+    twin.load_state(fresh.save_state())
+    c = scenes.make_cloud(rng, 5000, scenes.K640, scenes.SAMPLE_L2C, size, spec)
+    fresh.update(c), twin.update(c)
+    assert np.array_equal(fresh.read_image(fresh.DIFF), twin.read_image(twin.DIFF))
+    other = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), queue_size=5)
+    with pytest.raises(rmr.InvalidArgument):
+        other.load_state(blob)
+    with pytest.raises(rmr.InvalidArgument):
+        twin.load_state(blob[:100])
