@@ -256,6 +256,10 @@ rmr_status rmr_locator_search(rmr_locator* loc, rmr_robot* robots, int n);
  * robots against a kept slot: lets a batch of frames be located after a batched detect */
 rmr_status rmr_locator_keep(rmr_locator* loc, int frame);
 rmr_status rmr_locator_search_kept(rmr_locator* loc, int frame, rmr_robot* robots, int n);
+/* throughput mode: Locator::search over the kept frames 0 .. n_frames-1 in one pass (robots laid
+ * out as rmr_robot_detector_detect_batch returns them: cap per frame, counts[f] valid) */
+rmr_status rmr_locator_search_batch(rmr_locator* loc, rmr_robot* robots, const int* counts,
+                                    int n_frames, int cap);
 
 /* private members the reference's tests reach via `#define private public`
  * (test/locate/locator_test.cpp:6-13) */

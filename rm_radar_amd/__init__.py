@@ -446,6 +446,12 @@ class Locator:
         else:
             check(lib().rmr_locator_search_kept(self._h, frame, robots_c, n))
 
+    def search_batch_raw(self, robots_c, counts, cap: int):
+        """Throughput mode: search the kept frames 0..len(counts)-1 in one pass; `robots_c` is the
+        ctypes array RobotDetector.detect_batch_raw returned (cap robots per frame)."""
+        counts = np.ascontiguousarray(counts, np.int32)
+        check(lib().rmr_locator_search_batch(self._h, robots_c, _lib.ip(counts), len(counts), cap))
+
     # -- private members the reference's tests reach (locator_test.cpp:6-13)
     def read_image(self, which) -> np.ndarray:
         out = np.empty((self.hz, self.wz), np.float32)

@@ -271,6 +271,9 @@ rmr_status rmr_locator_read_image(rmr_locator* loc, int which, float* host_out) 
 rmr_status rmr_locator_write_image(rmr_locator* loc, int which, const float* host_in) {
     LOC_CALL(loc->impl.write_image(which, host_in));
 }
+rmr_status rmr_locator_search_batch(rmr_locator* loc, rmr_robot* robots, const int* counts, int n_frames, int cap) {
+    LOC_CALL(loc->impl.search_batch(robots, counts, n_frames, cap));
+}
 rmr_status rmr_locator_state_bytes(const rmr_locator* loc, size_t* bytes) {
     LOC_CALL(if (!bytes) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_locator_state_bytes: null argument");
              *bytes = loc->impl.state_bytes());

@@ -35,6 +35,9 @@ class Locator {
     void update(const float* xyz, int n, int stride_bytes, int mem);
     void cluster();
     void search(rmr_robot* robots, int n, int slot);  // slot -1 = current frame
+    // kept frames 0 .. n_frames-1 in one pass: robots[f * cap + i], i < counts[f]; one upload of the
+    // rects, one launch per frame, one download, ONE synchronisation
+    void search_batch(rmr_robot* robots, const int* counts, int n_frames, int cap);
     void keep(int frame);
 
     int width() const { return prm_.wz; }

@@ -795,6 +795,58 @@ void Locator::search(rmr_robot* robots, int n, int slot) {
     if (flags[0]) fail(RMR_ERR_CAPACITY, "Locator: foreground exceeded max_foreground=%d points", cfg_.max_foreground);
 }
 
+void Locator::search_batch(rmr_robot* robots, const int* counts, int n_frames, int cap) {
+    ctx_.use();
+    if (n_frames <= 0) return;
+    if (!robots || !counts || cap <= 0 || n_frames > cfg_.max_frames)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator::search_batch: bad arguments (frames %d of %d kept slots)", n_frames, cfg_.max_frames);
+    int total = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        if (counts[f] < 0 || counts[f] > cap) fail(RMR_ERR_INVALID_ARGUMENT, "Locator::search_batch: counts[%d] = %d", f, counts[f]);
+        total += counts[f];
+    }
+    if (total == 0) return;
+    rects_pin_.ensure((size_t)4 * total);
+    loc_pin_.ensure((size_t)4 * total);
+    rects_dev_.ensure((size_t)4 * total);
+    loc_dev_.ensure((size_t)4 * total);
+    int at = 0;
+    for (int f = 0; f < n_frames; ++f)
+        for (int i = 0; i < counts[f]; ++i, ++at) {
+            const rmr_robot& r = robots[(size_t)f * cap + i];
+            const int ri[4] = {cv_round(r.rect[0]), cv_round(r.rect[1]), cv_round(r.rect[2]), cv_round(r.rect[3])};
+            zoom(ri, rects_pin_.p + 4 * at);
+        }
+    RMR_HIP(hipMemcpyAsync(rects_dev_.p, rects_pin_.p, sizeof(int) * 4 * total, hipMemcpyHostToDevice, stream_));
+    const int nbuckets = max_clusters_ + 1;
+    at = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        if (!counts[f]) continue;
+        const FrameSlot& s = slots_[f + 1];
+        ProfScope ps(ctx_.prof, stream_, "loc_search", 0, 0);
+        loc_search<<<counts[f], 256, nbuckets * sizeof(int), stream_>>>(prm_, s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz,
+                                                                        s.fg_cluster, rects_dev_.p + 4 * at,
+                                                                        loc_dev_.p + 4 * at, nbuckets);
+        RMR_HIP(hipGetLastError());
+        at += counts[f];
+    }
+    RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * total, hipMemcpyDeviceToHost, stream_));
+    int flags[2] = {0, 0};
+    RMR_HIP(hipMemcpyAsync(flags, counters_.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+    at = 0;
+    for (int f = 0; f < n_frames; ++f)
+        for (int i = 0; i < counts[f]; ++i, ++at) {
+            const float* o = loc_pin_.p + 4 * at;
+            if (o[0] != 0) {
+                rmr_robot& r = robots[(size_t)f * cap + i];
+                r.has_location = 1;
+                r.location[0] = o[1], r.location[1] = o[2], r.location[2] = o[3];
+            }
+        }
+    if (flags[0]) fail(RMR_ERR_CAPACITY, "Locator: foreground exceeded max_foreground=%d points", cfg_.max_foreground);
+}
+
 float* Locator::image_ptr(int which) {
     switch (which) {
         case RMR_LOC_DEPTH: {

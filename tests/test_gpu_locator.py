@@ -248,3 +248,38 @@ def test_state_snapshot_resumes_a_stream(rmr, oracle, tmp_path):
         other.load_state(blob)
     with pytest.raises(rmr.InvalidArgument):
         twin.load_state(blob[:100])
+
+
+def test_search_batch_equals_per_frame_search(rmr):
+    # throughput mode: kept frames searched in one pass == Locator::search frame by frame
+    import ctypes as C
+    from rm_radar_amd import _lib
+    size, nf, cap = (640, 640), 5, 3
+    rng = np.random.default_rng(21)
+    loc = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), max_frames=nf)
+    loc.update(scenes.make_cloud(rng, 30000, scenes.K640, scenes.SAMPLE_L2C, size))
+    rects = [[(100, 300, 120, 90), (400, 200, 80, 120), (10, 10, 30, 30)][: f % 4] for f in range(nf)]
+    for f in range(nf):
+        spec = [(r, 2000.0, 250) for r in rects[f][:2]]
+        loc.update(scenes.make_cloud(rng, 20000, scenes.K640, scenes.SAMPLE_L2C, size, spec))
+        loc.cluster()
+        loc.keep(f)
+    def fill():
+        arr = (_lib.Robot * (nf * cap))()
+        for f in range(nf):
+            for i, r in enumerate(rects[f]):
+                arr[f * cap + i].rect[:] = [float(v) for v in r]
+        return arr
+    counts = np.array([len(r) for r in rects], np.int32)
+    a, b = fill(), fill()
+    loc.search_batch_raw(a, counts, cap)
+    for f in range(nf):
+        if counts[f]:
+            loc.search_raw(C.cast(C.addressof(b) + f * cap * C.sizeof(_lib.Robot), C.POINTER(_lib.Robot)), int(counts[f]), frame=f)
+    located = 0
+    for k in range(nf * cap):
+        assert a[k].has_location == b[k].has_location and tuple(a[k].location) == tuple(b[k].location)
+        located += a[k].has_location
+    assert located >= 4
+    with pytest.raises(rmr.InvalidArgument):
+        loc.search_batch_raw(a, np.array([cap + 1] * nf, np.int32), cap)
