@@ -74,7 +74,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     constexpr int B_TAP_BYTES = BN * 64;
     constexpr int B_STAGE_BYTES = B_TAP_BYTES * TPS;
     static_assert(TPS == 1 || TPS == 3 || TPS == 9, "a slice is 1, 3 or 9 taps");
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
     static_assert((BSTAGES - 1) * NI <= 63, "vmcnt is 6 bits");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -332,6 +332,11 @@ const HaloTile kHaloTiles[] = {
     HTILE_T(4, 2, 2, 6, 6, 3),   // 25: 128 x 192
     HTILE_T(4, 2, 4, 6, 8, 3),   // 26: 256 x 192
     HTILE_T(4, 2, 4, 3, 10, 3),  // 27: 256 x 96
+    // 16 waves: two 128-pixel halves share one weight ring (half the weight DMA per MAC at the
+    // occupancy of two 8-wave workgroups)
+    HTILE_T(8, 2, 2, 6, 4, 1),   // 28: 256 x 192
+    HTILE_T(8, 2, 2, 3, 6, 1),   // 29: 256 x 96
+    HTILE_T(8, 2, 2, 9, 4, 1),   // 30: 256 x 288
 };
 constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
 
