@@ -43,11 +43,15 @@ constexpr int WS_W = 160;                      // map width
 constexpr int WS_PIX = WS_C * 2;               // bytes per pixel in LDS
 constexpr int WS_ROW = (WS_W + 2) * WS_PIX;    // ring slot: zero pixel, row, zero pixel
 constexpr int WS_SLOTS = 8;
-constexpr int WS_STAGE = 8192;                   // per-wave output / residual stage: 80 pixels x 96 B, padded to 8 DMA KiB
 constexpr int WS_KSTEPS = 14;                  // ceil(9 * 48 / 32)
 constexpr int WS_DMA_ROW = WS_W * WS_PIX / 1024;  // 15 DMA instructions per row
-constexpr int WS_NI = 8;                       // DMA instructions per wave per row pair (30 -> 8,8,7,7 + idle)
-constexpr int WS_LDS = WS_SLOTS * WS_ROW + 4 * WS_STAGE + 1024;  // + one KiB that idle DMA slots land in
+// NJ = 1: 4 waves, each all 48 output channels (weights 168 VGPRs, one wave per SIMD).
+// NJ = 3: 12 waves, wave (row, half, j) computes channel tile j only (weights 56 VGPRs, three waves
+// per SIMD): every input fragment is read three times from LDS, but one wave's epilogue and waits
+// now hide under the other two waves' MFMAs.
+constexpr int ws_ni(int nj) { return (2 * WS_DMA_ROW + 4 * nj - 1) / (4 * nj); }  // DMA instructions per wave per row pair
+constexpr int ws_stage(int nj) { return ws_ni(nj) * 1024; }  // per-wave stage: 80 pixels x (96 / NJ) bytes, padded to whole DMA KiB
+constexpr int ws_lds(int nj) { return WS_SLOTS * WS_ROW + 4 * nj * ws_stage(nj) + 1024; }  // + one KiB that idle DMA slots land in
 
 // v * rcp(1 + e^-v): the hardware reciprocal (1 ulp) instead of an IEEE division, 60 per step per lane
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -65,9 +69,15 @@ __device__ __forceinline__ void wait_vmw() {
 }
 
 // strip_rows: output rows per workgroup (even, divides H)
-template <bool ACT, bool RES, bool OUT32>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <bool ACT, bool RES, bool OUT32, int NJ>
+__global__ __launch_bounds__(256 * NJ) __attribute__((amdgpu_waves_per_eu(NJ, NJ)))
 void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
+    constexpr int NW = 4 * NJ;              // waves
+    constexpr int NT = 3 / NJ;              // 16-channel tiles per wave
+    constexpr int WS_NI = ws_ni(NJ);
+    constexpr int WS_STAGE = ws_stage(NJ);
+    constexpr int CPP = NT * 2;             // 16-byte chunks per pixel in a wave's stage
+    static_assert(NJ == 1 || NJ == 3, "1 or 3 wave groups along the output channels");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(
         (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
@@ -76,8 +86,9 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = wave >> 1;          // output row of the step this wave computes
-    const int xh = wave & 1;          // left / right half of the row
+    const int grp = wave / NJ, jw = wave % NJ;
+    const int r = grp >> 1;           // output row of the step this wave computes
+    const int xh = grp & 1;           // left / right half of the row
     const int frow = lane & 15;
     const int kg = lane >> 4;
     const bool hi = kg >= 2;          // lanes 32-63 take the second 16 k of a K step
@@ -89,10 +100,10 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
 
     const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
                            sgpr(a.in_bytes), sgpr(0x00020000u)};
-    const unsigned scratch = sgpr(lds0 + WS_SLOTS * WS_ROW + 4 * WS_STAGE);
+    const unsigned scratch = sgpr(lds0 + WS_SLOTS * WS_ROW + NW * WS_STAGE);
 
     // ---- zero the edge pixels of every ring slot (never written again) -------------------------
-    for (int i = tid; i < WS_SLOTS * 2 * (WS_PIX / 16); i += 256) {
+    for (int i = tid; i < WS_SLOTS * 2 * (WS_PIX / 16); i += 64 * NW) {
         const int slot = i / (2 * (WS_PIX / 16));
         const int rem = i % (2 * (WS_PIX / 16));
         const int side = rem / (WS_PIX / 16), c16 = rem % (WS_PIX / 16);
@@ -101,25 +112,25 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
     __syncthreads();
 
     // ---- the filter, as B fragments, for the whole kernel ---------------------------------------
-    half8 wreg[WS_KSTEPS][3];
+    half8 wreg[WS_KSTEPS][NT];
 #pragma unroll
     for (int ks = 0; ks < WS_KSTEPS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            wreg[ks][j] = *(const half8*)((const _Float16*)a.wt + (size_t)(j * 16 + frow) * a.Kp + ks * 32 + kg * 8);
+        for (int j = 0; j < NT; ++j)
+            wreg[ks][j] = *(const half8*)((const _Float16*)a.wt + (size_t)((jw * NT + j) * 16 + frow) * a.Kp + ks * 32 + kg * 8);
     // opaque to the optimiser from here on: otherwise it re-loads fragments from memory inside the
     // step loop (rematerialisation) instead of keeping them in registers
 #pragma unroll
     for (int ks = 0; ks < WS_KSTEPS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(wreg[ks][j]));
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(wreg[ks][j]));
 
     // ---- DMA bookkeeping: relative row ry (0 = y_base - 1) lives in ring slot ry % 8 ----------
-    // slot q = wave + 4 j of a row pair: row q / 15 of the pair, instruction q % 15 of that row
+    // slot q = wave + NW j of a row pair: row q / 15 of the pair, instruction q % 15 of that row
     unsigned goff[WS_NI];
 #pragma unroll
     for (int j = 0; j < WS_NI; ++j) {
-        const int q = wave + 4 * j;
+        const int q = wave + NW * j;
         const int g = (q % WS_DMA_ROW) * 64 + lane;  // 16-byte chunk within the row
         goff[j] = (unsigned)(((g / 6) * a.in_cs + a.in_co + (g % 6) * 8) * 2);
     }
@@ -129,7 +140,7 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
     unsigned q_ok[WS_NI], q_row[WS_NI], q_dst[WS_NI];
 #pragma unroll
     for (int j = 0; j < WS_NI; ++j) {
-        const int q = wave + 4 * j;
+        const int q = wave + NW * j;
         q_ok[j] = q < 2 * WS_DMA_ROW ? 0xffffffffu : 0u;
         q_row[j] = q >= WS_DMA_ROW ? 0xffffffffu : 0u;
         q_dst[j] = (unsigned)(WS_PIX + (q % WS_DMA_ROW) * 1024);
@@ -171,9 +182,9 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
 #pragma unroll
     for (int t = 0; t < WS_NI; ++t) {
         const int c = lane + 64 * t;
-        cmask[t] = c < 80 * 6 ? 0xffffffffu : 0u;
-        ooff[t] = (unsigned)(((c / 6) * a.out_cs + a.out_co + (c % 6) * 8) * 2);
-        roff[t] = (unsigned)(((c / 6) * a.res_cs + a.res_co + (c % 6) * 8) * 2);
+        cmask[t] = c < 80 * CPP ? 0xffffffffu : 0u;
+        ooff[t] = (unsigned)(((c / CPP) * a.out_cs + a.out_co + jw * NT * 16 + (c % CPP) * 8) * 2);
+        roff[t] = (unsigned)(((c / CPP) * a.res_cs + a.res_co + jw * NT * 16 + (c % CPP) * 8) * 2);
     }
     const u32x4 res_rsrc = {sgpr((unsigned)(size_t)a.res), sgpr((unsigned)((size_t)a.res >> 32) & 0xffffu),
                             sgpr(0xffffffffu), sgpr(0x00020000u)};
@@ -188,9 +199,9 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
             if (cmask[t]) *(u32x4*)((unsigned char*)a.out + m_row * a.out_cs * 2 + ooff[t]) = v[t];
     };
 
-    float4 bias[3];
+    float4 bias[NT];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) bias[j] = *(const float4*)(a.bias + j * 16 + cq);
+    for (int j = 0; j < NT; ++j) bias[j] = *(const float4*)(a.bias + (jw * NT + j) * 16 + cq);
 
     // fragment reads of K step ks: k = 32 ks + 8 kg, lanes 0-31 start at kL, lanes 32-63 at
     // kH = kL + 16 (same or next tap); k >= 432 meets zero weights, so it re-reads finite data
@@ -229,11 +240,11 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) vb[kh] = lds0 + ((2 * s + r + kh) % WS_SLOTS) * WS_ROW + lane_off;
 
-        floatx4 acc[5][3];
+        floatx4 acc[5][NT];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
         half8 xf[2][5];
         read_frags(0, xf[0]);
@@ -244,7 +255,7 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -254,15 +265,15 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int n = j * 16 + cq;
+            for (int j = 0; j < NT; ++j) {
+                const int n = (jw * NT + j) * 16 + cq;
                 const float4 b = bias[j];
                 float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
                 if (ACT) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = silu_w(v[e]);
                 }
-                unsigned char* const sp = stage_p + (i * 16 + px) * WS_PIX + n * 2;
+                unsigned char* const sp = stage_p + (i * 16 + px) * (CPP * 16) + (j * 16 + cq) * 2;
                 if (RES) {
                     union {
                         uint2 u;
@@ -290,8 +301,10 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
     wait_vmw<0>();
 }
 
+// variant = strip height x wave layout (NJ = 1 for ids 0..5, NJ = 3 for ids 6..11)
 const int kWsStripRows[] = {40, 20, 10, 8, 4, 2};
-constexpr int kNumWs = sizeof(kWsStripRows) / sizeof(kWsStripRows[0]);
+constexpr int kNumStrips = sizeof(kWsStripRows) / sizeof(kWsStripRows[0]);
+constexpr int kNumWs = 2 * kNumStrips;
 
 }  // namespace
 
@@ -302,7 +315,7 @@ bool conv_ws_supported(const ConvArgs& a, int variant) {
     if (a.Cin != WS_C || a.Cout_pad != WS_C || a.W != WS_W || a.Wo != a.W || a.Ho != a.H) return false;
     if (a.Kp < WS_KSTEPS * 32 || (!a.out32 && !a.out)) return false;
     if (variant < 0) return a.H % 2 == 0;
-    return variant < kNumWs && a.H % kWsStripRows[variant] == 0;
+    return variant < kNumWs && a.H % kWsStripRows[variant % kNumStrips] == 0;
 }
 
 void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant) {
@@ -312,17 +325,22 @@ void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
         fail(RMR_ERR_LOGIC, "conv_ws: misaligned view");
     if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull) fail(RMR_ERR_LOGIC, "conv_ws: input view size not set or larger than 3.75 GiB");
     using Kern = void (*)(const ConvArgs, int);
-    static const Kern kernels[8] = {conv_ws_kernel<false, false, false>, conv_ws_kernel<false, false, true>,
-                                    conv_ws_kernel<false, true, false>,  conv_ws_kernel<false, true, true>,
-                                    conv_ws_kernel<true, false, false>,  conv_ws_kernel<true, false, true>,
-                                    conv_ws_kernel<true, true, false>,   conv_ws_kernel<true, true, true>};
+#define WS_KERNELS(NJ)                                                                                   \
+    {conv_ws_kernel<false, false, false, NJ>, conv_ws_kernel<false, false, true, NJ>,                    \
+     conv_ws_kernel<false, true, false, NJ>,  conv_ws_kernel<false, true, true, NJ>,                     \
+     conv_ws_kernel<true, false, false, NJ>,  conv_ws_kernel<true, false, true, NJ>,                     \
+     conv_ws_kernel<true, true, false, NJ>,   conv_ws_kernel<true, true, true, NJ>}
+    static const Kern kernels[2][8] = {WS_KERNELS(1), WS_KERNELS(3)};
+#undef WS_KERNELS
     static std::once_flag once;
     std::call_once(once, [] {
-        for (Kern k : kernels)
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (const auto& row : kernels)
+            for (Kern k : row)
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    const Kern kernel = kernels[(a.act ? 4 : 0) + (a.res ? 2 : 0) + (a.out32 ? 1 : 0)];
-    const int sr = kWsStripRows[variant];
+    const int nj = variant < kNumStrips ? 1 : 3;
+    const Kern kernel = kernels[nj == 1 ? 0 : 1][(a.act ? 4 : 0) + (a.res ? 2 : 0) + (a.out32 ? 1 : 0)];
+    const int sr = kWsStripRows[variant % kNumStrips];
     const int grid = a.N * (a.H / sr);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
@@ -337,7 +355,7 @@ void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
         pname = names.emplace(buf, buf).first->second.c_str();
     }
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
-    kernel<<<grid, 256, WS_LDS, stream>>>(a, sr);
+    kernel<<<grid, 256 * nj, ws_lds(nj), stream>>>(a, sr);
     RMR_HIP(hipGetLastError());
 }
 

@@ -145,12 +145,15 @@ def test_conv_halo_every_tile(rmr):
 def test_conv_weights_stationary(rmr):
     # conv_ws.hip (ids 300..): 3x3 / s1, 48 -> 48 channels on 160-wide maps; the filter stays in
     # registers and a workgroup walks a strip of rows through an LDS ring.  Variants = strip heights.
-    for v, rows in enumerate([40, 20, 10, 8, 4, 2]):
+    for v, rows in enumerate([40, 20, 10, 8, 4, 2] * 2):   # ids 0..5: 4 waves x all channels; 6..11: 12 waves x one channel tile
         run_case(rmr, 2, 40, 160, 48, 48, 3, 1, True, True, tile=300 + v, seed=80 + v)   # 2 images, H = 40
     run_case(rmr, 1, 160, 160, 48, 48, 3, 1, True, False, tile=300, seed=90)   # 4 strips of 40 rows, no residual
     run_case(rmr, 3, 6, 160, 48, 48, 3, 1, False, True, tile=305, seed=91)     # strips of 2 rows, H = 6: ring wraps at image ends
     run_case(rmr, 1, 10, 160, 48, 48, 3, 1, True, True, tile=302, seed=92)     # one strip = whole image
     run_case(rmr, 1, 20, 160, 48, 41, 3, 1, True, True, tile=301, seed=93)     # 41 channels padded to 48
+    run_case(rmr, 1, 160, 160, 48, 48, 3, 1, True, True, tile=306, seed=94)    # 12-wave layout, 4 strips, residual
+    run_case(rmr, 3, 6, 160, 48, 48, 3, 1, False, False, tile=311, seed=95)    # 12-wave layout, 2-row strips
+    run_case(rmr, 1, 20, 160, 48, 41, 3, 1, True, False, tile=307, seed=96)    # 12-wave layout, padded channels
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 8, 80, 48), np.float32), np.zeros((48, 48, 3, 3), np.float32), None, 1, 1,
                    False, tile=300)  # W != 160
