@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--crops", type=int, default=4)   # K: kOptBatchSize, sample_radar.h:34
     ap.add_argument("--points", type=int, default=30000)
-    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--size", type=int, default=640, help="frame width (and height unless --height is given)")
+    ap.add_argument("--height", type=int, default=0, help="frame height, e.g. --size 1920 --height 1080 for configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
@@ -51,29 +52,44 @@ def parse():
     return ap.parse_args()
 
 
+def frame_size(args):
+    return (args.size, args.height or args.size)
+
+
+def intrinsic(args):
+    """640x640: the survey's K; other sizes: the same 66-degree horizontal field of view."""
+    import scenes
+    w, h = frame_size(args)
+    if (w, h) == (640, 640):
+        return scenes.K640
+    f = 416.0 * w / 640.0
+    return np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
+
+
 def crop_rects(rng, n_frames, k, size):
+    W, H = size
     out = np.zeros((n_frames, k, 4), np.int32)
     for f in range(n_frames):
         for i in range(k):
-            w = int(rng.integers(size // 8, size // 3))
-            h = int(rng.integers(size // 8, size // 3))
-            out[f, i] = (int(rng.integers(0, size - w)), int(rng.integers(0, size - h)), w, h)
+            w = int(rng.integers(W // 8, W // 3))
+            h = int(rng.integers(H // 8, H // 3))
+            out[f, i] = (int(rng.integers(0, W - w)), int(rng.integers(0, H - h)), w, h)
     return out
 
 
 def make_inputs(args, rank):
     """BATCH frames of one camera/LiDAR stream: images + clouds + robot rects (numpy)."""
     import scenes
-    size = (args.size, args.size)
+    size = frame_size(args)
     rng = np.random.default_rng(100 + rank)
-    rects = crop_rects(rng, args.batch, args.crops, args.size)
+    rects = crop_rects(rng, args.batch, args.crops, size)
     images = np.stack([scenes.synthetic_image(rank * 10000 + f, size) for f in range(args.batch)])
     clouds = np.zeros((args.batch, args.points, 4), np.float32)
     crng = np.random.default_rng(200 + rank)
     for f in range(args.batch):
         robots = [(tuple(float(v) for v in r), float(crng.uniform(1000, 3000)), int(crng.integers(40, 400)))
                   for r in rects[f]] if f >= 2 else []
-        clouds[f] = scenes.make_cloud(crng, args.points, scenes.K640, scenes.SAMPLE_L2C, size, robots)
+        clouds[f] = scenes.make_cloud(crng, args.points, intrinsic(args), scenes.SAMPLE_L2C, size, robots)
     return images, clouds, rects
 
 
@@ -86,7 +102,7 @@ def cpu_baseline(args, packs, images, clouds, rects):
     import scenes
     from oracle import yolov8_ref as R
     car, armor = R.load(packs[0]), R.load(packs[1])
-    loc = oracle.Locator(args.size, args.size, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+    loc = oracle.Locator(*frame_size(args), intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
     n = max(1, args.cpu_frames)
     t0 = time.perf_counter()
     for f in range(n):
@@ -137,7 +153,7 @@ def main():
     W.make_synthetic_pack(packs[1], "m", 12, seed=2, cls_bias=-6.0)
 
     images, clouds, rects = make_inputs(args, rank)
-    size = (args.size, args.size)
+    size = frame_size(args)
     d_images = torch.from_numpy(images).to(dev)
     d_clouds = torch.from_numpy(clouds).to(dev)
     img_list = [d_images[f] for f in range(args.batch)]
@@ -145,43 +161,28 @@ def main():
     B, K = args.batch, args.crops
     rdet = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1),
                              device=local, max_frames=B)
-    loc = rmr.Locator(args.size, args.size, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32),
+    loc = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32),
                       device=local, max_frames=B)
     cap = rdet.max_cars
     flops_frame = W.flops_per_image("m", 1) + K * W.flops_per_image("m", 12)
 
     import ctypes as C
     from rm_radar_amd import _lib
-    phases = {"locate_enqueue": 0.0, "detect": 0.0, "search": 0.0, "pack_gather": 0.0}
+    phases = {"detect_locate_search": 0.0, "pack_gather": 0.0}
 
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=1)
-
-    def locate_all():
-        t = time.perf_counter()
-        for f in range(B):  # stream order: the Locator carries temporal state
-            loc.update(d_clouds[f])
-            loc.cluster()
-            loc.keep(f)
-        return time.perf_counter() - t
+    cloud_list = [d_clouds[f] for f in range(B)]
 
     def step():
-        # the reference's call order (sample_radar.h:106-127): update + cluster on one thread while
-        # detect runs on another, join, then search
+        # one native call in the reference's order (sample_radar.h:106-127): update + cluster of
+        # the 64 frames on a helper thread while detect runs, join, then one batched search
         t0 = time.perf_counter()
-        fut = pool.submit(locate_all)
-        robots, counts = rdet.detect_batch_raw(img_list, rects)
-        t_loc = fut.result()
-        t2 = time.perf_counter()
-        loc.search_batch_raw(robots, counts, cap)
+        robots, counts = rmr.run_batch(rdet, loc, img_list, cloud_list, rects)
         t3 = time.perf_counter()
         block = torch.from_numpy(rd.pack_records(robots, counts, cap, rank, cap))
         if use_dist:
             block = rd.all_gather_records(block.to(dev), force=True)
         t4 = time.perf_counter()
-        phases["locate_enqueue"] += t_loc
-        phases["detect"] += t2 - t0
-        phases["search"] += t3 - t2
+        phases["detect_locate_search"] += t3 - t0
         phases["pack_gather"] += t4 - t3
         return block, counts
 
@@ -222,7 +223,7 @@ def main():
     traffic, traffic_src = None, None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
-        if B == 64 and K == 4 and args.size == 640:
+        if B == 64 and K == 4 and size == (640, 640):
             traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/r01_pmc_conv_traffic.json"
     except (OSError, KeyError, ValueError):
         pass
@@ -246,7 +247,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: batch={B} synthetic {args.size}x{args.size} frames + "
+            "config": {"workload": f"{'configs[2]' if size == (640, 640) else 'configs[3] shape'}: batch={B} synthetic {size[0]}x{size[1]} frames + "
                                    f"{args.points}-pt clouds per step per GPU, car YOLOv8m + {K} injected "
                                    f"armor crops/frame (YOLOv8m, nc=12), seeded synthetic weights, f16 MFMA",
                        "frames_per_step_per_gpu": B, "crops_per_frame": K, "points_per_cloud": args.points,
@@ -270,9 +271,9 @@ def main():
         rdet.close()
         loc.close()
         r1 = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1), device=local)
-        l1 = rmr.Locator(args.size, args.size, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=local)
+        l1 = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=local)
         lat = []
-        for i in range(60):
+        for i in range(220):  # 20 warm-up + 200 timed frames
             f = i % B
             t0 = time.perf_counter()
             l1.update(clouds[f])
@@ -280,7 +281,7 @@ def main():
             rb = r1.detect_batch([images[f]], forced_crops=[rects[f]])[0]
             l1.search(rb)
             lat.append((time.perf_counter() - t0) * 1e3)
-        lat = np.array(lat[10:])
+        lat = np.array(lat[20:])
         result["p50_ms_batch1"] = round(float(np.percentile(lat, 50)), 3)
         result["p99_ms_batch1"] = round(float(np.percentile(lat, 99)), 3)
         r1.close()

@@ -283,6 +283,17 @@ rmr_status rmr_locator_foreground(rmr_locator* loc, float* xyz, int* pixel, int*
                                   int* n);
 int rmr_locator_num_clusters(rmr_locator* loc);
 
+/* ---------------------------------------------------------------- whole path, throughput mode
+ * SampleRadar::runOnce (samples/sample_radar.h:106-127) over n_frames frames of ONE stream:
+ * Locator update + cluster of every frame (in order) on a helper thread while the two-stage
+ * detect runs, join, then one batched search.  clouds[f] / n_points[f]: the frame's points as
+ * rmr_locator_update takes them; forced_crops as in rmr_robot_detector_detect_batch; the locator
+ * must have been created with max_frames >= n_frames.  out: cap robots per frame, located. */
+rmr_status rmr_pipeline_run_batch(rmr_robot_detector* rd, rmr_locator* loc, const rmr_image* imgs,
+                                  const float* const* clouds, const int* n_points, int stride_bytes,
+                                  int mem, int n_frames, const int* forced_crops, int forced_per_frame,
+                                  rmr_robot* out, int* n_out, int cap);
+
 /* ---------------------------------------------------------------- per-kernel profile */
 
 /* HIP-event timing of the library's own launches, on the streams they run on */

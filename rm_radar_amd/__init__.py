@@ -20,7 +20,7 @@ from ._lib import (CapacityError, DET_DTYPE, DeviceError, InvalidArgument, PrePa
 __all__ = ["Detector", "RobotDetector", "Locator", "Robot", "PreParam", "preparam",
            "letterbox_geometry", "letterbox", "preprocess", "postprocess", "transpose",
            "conv2d", "restore_detection", "device_count", "profile", "DET_DTYPE", "RmrError",
-           "Tracker", "KalmanFilter", "SingerEKF", "auction", "TRACK_TENTATIVE", "TRACK_CONFIRMED", "TRACK_DELETED",
+           "run_batch", "Tracker", "KalmanFilter", "SingerEKF", "auction", "TRACK_TENTATIVE", "TRACK_CONFIRMED", "TRACK_DELETED",
            "InvalidArgument", "DeviceError", "CapacityError", "Label"]
 
 # radar::Label (src/robot/robot.h:32-45)
@@ -521,6 +521,53 @@ class Locator:
 
 
 # ------------------------------------------------------------------------------- profiling
+
+# ------------------------------------------------------------------------------- whole path
+
+def run_batch(robot_detector: "RobotDetector", locator: "Locator", images, clouds, forced_crops=None):
+    """Throughput mode of SampleRadar::runOnce (sample_radar.h:106-127) over the frames of ONE
+    stream in one native call: update + cluster of every cloud on a helper thread while the
+    two-stage detect runs, then one batched search.  `clouds`: per frame a [n, >=3] f32 device
+    tensor or numpy array (all of one kind, same row stride).  Returns (ctypes Robot array
+    [n_frames * max_cars], counts) like RobotDetector.detect_batch_raw, robots located."""
+    imgs = list(images)
+    n = len(imgs)
+    if len(clouds) != n:
+        raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: one cloud per image")
+    arr, _, keep = _images(imgs, None)
+    device = _is_device_tensor(clouds[0])
+    ptrs = (_lib._fp * n)()
+    npts = np.zeros(n, np.int32)
+    stride = None
+    for f, c in enumerate(clouds):
+        if _is_device_tensor(c) != device:
+            raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: clouds must be all device or all host")
+        if device:
+            if c.dim() != 2 or c.shape[1] < 3 or c.element_size() != 4 or c.stride(1) != 1:
+                raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "device cloud must be [n, >=3] f32")
+            p, st = c.data_ptr(), c.stride(0) * 4
+        else:
+            c = np.ascontiguousarray(c, np.float32)
+            keep.append(c)
+            p, st = c.ctypes.data, c.strides[0]
+        if stride is None:
+            stride = st
+        elif st != stride and c.shape[0] > 0:
+            raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: clouds must share one row stride")
+        ptrs[f] = C.cast(p, _lib._fp)
+        npts[f] = c.shape[0]
+    cap = robot_detector.max_cars
+    out = (_lib.Robot * (cap * n))()
+    counts = np.zeros(n, np.int32)
+    fc, per = None, 0
+    if forced_crops is not None:
+        fc = np.ascontiguousarray(np.asarray(forced_crops, np.int32).reshape(n, -1, 4))
+        per = fc.shape[1]
+    check(lib().rmr_pipeline_run_batch(robot_detector._h, locator._h, arr, ptrs, _lib.ip(npts), stride or 16,
+                                       _lib.MEM_DEVICE if device else _lib.MEM_HOST, n,
+                                       _lib.ip(fc) if fc is not None else None, per, out, _lib.ip(counts), cap))
+    return out, counts
+
 
 # ------------------------------------------------------------------------------- Tracker (host)
 

@@ -167,6 +167,8 @@ SYMBOLS = {
     "rmr_locator_zoom": (C.c_int, [_vp, _ip, _ip]),
     "rmr_locator_foreground": (C.c_int, [_vp, _fp, _ip, _ip, C.c_int, _ip]),
     "rmr_locator_num_clusters": (C.c_int, [_vp]),
+    "rmr_pipeline_run_batch": (C.c_int, [_vp, _vp, _P(Image), _P(_fp), _ip, C.c_int, C.c_int, C.c_int, _ip, C.c_int,
+                                         _P(Robot), _ip, C.c_int]),
     "rmr_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "rmr_profile_reset": (C.c_int, [C.c_int]),
     "rmr_profile_read": (C.c_int, [C.c_int, _P(KernelStat), C.c_int, _ip]),

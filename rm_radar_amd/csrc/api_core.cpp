@@ -1,5 +1,6 @@
 // api_core.cpp -- C-ABI entry points (include/rmr.h) for geometry, the unit kernels, the
 // Locator and the host-side Robot assembly.  Detector entry points live in api_detect.cpp.
+#include "api_handles.h"
 #include "common.h"
 #include "locator.h"
 #include "postprocess.h"
@@ -213,11 +214,6 @@ rmr_status rmr_group_robots(const rmr_robot* in, int n, float iou_thresh, rmr_ro
 }
 
 // ---- Locator ---------------------------------------------------------------------------
-
-struct rmr_locator {
-    Locator impl;
-    explicit rmr_locator(const rmr_locator_cfg& c) : impl(c) {}
-};
 
 // locator.h:59-65 defaults
 void rmr_locator_cfg_default(rmr_locator_cfg* c) {

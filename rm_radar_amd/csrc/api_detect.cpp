@@ -4,18 +4,9 @@
 
 #include "common.h"
 #include "conv_igemm.h"
-#include "detector.h"
+#include "api_handles.h"
 
 using namespace rmr;
-
-struct rmr_detector {
-    Detector impl;
-    explicit rmr_detector(const rmr_detector_cfg& c) : impl(c) {}
-};
-struct rmr_robot_detector {
-    RobotDetector impl;
-    explicit rmr_robot_detector(const rmr_robot_detector_cfg& c) : impl(c) {}
-};
 
 extern "C" {
 

@@ -12,7 +12,7 @@ namespace rmr {
 // Keeps device copies of host frames for the duration of one detect call.
 class FrameStage {
    public:
-    explicit FrameStage(DeviceCtx& ctx) : ctx_(ctx) {}
+    explicit FrameStage(DeviceCtx&) {}
     // returns, per image, a device pointer + geometry (device images pass through)
     struct Frame {
         const uint8_t* dev;
@@ -21,7 +21,6 @@ class FrameStage {
     const std::vector<Frame>& stage(hipStream_t s, const rmr_image* imgs, int n);
 
    private:
-    DeviceCtx& ctx_;
     DevBuf<uint8_t> dev_;
     PinnedBuf<uint8_t> pin_;
     std::vector<Frame> frames_;

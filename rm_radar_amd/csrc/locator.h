@@ -76,6 +76,7 @@ class Locator {
     // cluster() scratch
     DevBuf<int> blk_count_, blk_offset_;
     DevBuf<int> parent_, csize_, vroot_, vsize_, root_id_, counters_;
+    DevBuf<float> fg_depth_;  // camera depth of each foreground point (prunes the pair tests of cluster())
     DevBuf<int> store_int_;
     DevBuf<float> store_f_;
     std::vector<FrameSlot> slots_;  // [0] = current frame, [1+f] = kept frame f

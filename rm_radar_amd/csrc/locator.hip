@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void fg_scan(const int* __restrict__ blk_coun
 __global__ __launch_bounds__(256) void fg_compact(LocParams P, const float* __restrict__ diff,
                                                   size_t npx, const int* __restrict__ blk_offset,
                                                   int max_fg, int* __restrict__ fg_pixel,
-                                                  float* __restrict__ fg_xyz) {
+                                                  float* __restrict__ fg_xyz, float* __restrict__ fg_depth) {
     __shared__ int wtot[4];
     const size_t base = (size_t)blockIdx.x * FG_PX_PER_BLOCK + (size_t)threadIdx.x * 4;
     float val[4];
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void fg_compact(LocParams P, const float* __re
                 float o[3];
                 camera_to_lidar(P, uvd, o);
                 fg_pixel[dst] = (int)p;
+                fg_depth[dst] = val[j];
                 fg_xyz[dst * 3 + 0] = o[0];
                 fg_xyz[dst * 3 + 1] = o[1];
                 fg_xyz[dst * 3 + 2] = o[2];
@@ -246,6 +247,16 @@ __global__ __launch_bounds__(256) void fg_compact(LocParams P, const float* __re
 // union, flatten, size filter, ranking and id assignment with the union-find forest in LDS
 // (n <= CC_LDS_MAX) -- LDS atomics instead of L2 round trips -- or, for larger n, the same code
 // over the global scratch arrays.
+//
+// The pair tests are pruned with the ordering of the list: points are in row-major pixel order and
+// two points closer than the tolerance cannot be more than R rows apart.  In the camera frame (the
+// lidar frame is a rigid image of it) a point reconstructed from pixel row v at depth d has
+// y = d (v / zoom - cy) / fy, so for |p - q| < tol:
+//   |v_p - v_q| = zoom fy |y_p / d_p - y_q / d_q| < zoom fy tol / d_p * (1 + |y_q| / d_q),
+// and |y_q| / d_q <= max(cy, H - cy) / fy.  Point i therefore only meets the candidates j < i whose
+// row is within R_i = floor(row_k / d_i) + 1 of its own: a contiguous tail of the list, found by
+// binary search.  The partition is exactly the all-pairs one (every pair within the tolerance is
+// still tested); d_i <= 0 or a skewed intrinsic (row_k <= 0) falls back to all pairs.
 constexpr int CC_THREADS = 1024;
 constexpr int CC_LDS_MAX = 4096;
 
@@ -270,7 +281,8 @@ __device__ __forceinline__ int cc_find(volatile int* parent, int x) {
 template <bool SMALL>
 __device__ void cc_block(int n, const float* __restrict__ xyz, float tol2, int min_size, int max_size,
                          volatile int* parent, int* csize, int* root_id, int* vroot, int* vsize,
-                         const float* lxyz, int* nvalid, int* __restrict__ fg_cluster) {
+                         const float* lxyz, int* nvalid, int* __restrict__ fg_cluster, const int* pix,
+                         const float* __restrict__ depth, float row_k, int wz) {
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += CC_THREADS) {
         parent[i] = i;
@@ -284,7 +296,24 @@ __device__ void cc_block(int n, const float* __restrict__ xyz, float tol2, int m
     for (int i = tid; i < n; i += CC_THREADS) {
         const float ax = src[i * 3 + 0], ay = src[i * 3 + 1], az = src[i * 3 + 2];
         int my_root = i;
-        for (int j = 0; j < i; ++j) {
+        int j0 = 0;
+        const float d_i = depth[i];
+        if (row_k > 0.f && d_i > 0.f) {
+            const float rows = row_k / d_i;
+            if (rows < 1.0e6f) {
+                const int v_lo = pix[i] / wz - ((int)rows + 1);
+                if (v_lo > 0) {  // first j with pixel >= v_lo * wz
+                    const int key = v_lo * wz;
+                    int lo = 0, hi = i;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (pix[mid] < key) lo = mid + 1; else hi = mid;
+                    }
+                    j0 = lo;
+                }
+            }
+        }
+        for (int j = j0; j < i; ++j) {
             const float dx = src[j * 3 + 0] - ax, dy = src[j * 3 + 1] - ay, dz = src[j * 3 + 2] - az;
             const float d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < tol2) {
@@ -338,7 +367,9 @@ __global__ __launch_bounds__(CC_THREADS) void cc_fused(int* __restrict__ counter
                                                        float tol2, int min_size, int max_size,
                                                        int* g_parent, int* g_csize, int* g_root_id, int* g_vroot,
                                                        int* g_vsize, int* __restrict__ fg_cluster,
-                                                       int* __restrict__ slot_n_clusters) {
+                                                       int* __restrict__ slot_n_clusters,
+                                                       const int* __restrict__ fg_pixel,
+                                                       const float* __restrict__ fg_depth, float row_k, int wz) {
     extern __shared__ __attribute__((aligned(16))) int cc_lds[];
     __shared__ int nvalid;
     const int n = counters[0];
@@ -349,12 +380,15 @@ __global__ __launch_bounds__(CC_THREADS) void cc_fused(int* __restrict__ counter
         int* vroot = cc_lds + 3 * CC_LDS_MAX;    // [CC_LDS_MAX]
         int* vsize = cc_lds + 4 * CC_LDS_MAX;    // [CC_LDS_MAX]
         float* lxyz = (float*)(cc_lds + 5 * CC_LDS_MAX);  // [3 * CC_LDS_MAX]
+        int* lpix = cc_lds + 8 * CC_LDS_MAX;              // [CC_LDS_MAX]
         for (int i = threadIdx.x; i < 3 * n; i += CC_THREADS) lxyz[i] = xyz[i];
+        for (int i = threadIdx.x; i < n; i += CC_THREADS) lpix[i] = fg_pixel[i];
         __syncthreads();
-        cc_block<true>(n, xyz, tol2, min_size, max_size, parent, csize, root_id, vroot, vsize, lxyz, &nvalid, fg_cluster);
+        cc_block<true>(n, xyz, tol2, min_size, max_size, parent, csize, root_id, vroot, vsize, lxyz, &nvalid, fg_cluster,
+                       lpix, fg_depth, row_k, wz);
     } else {
         cc_block<false>(n, xyz, tol2, min_size, max_size, g_parent, g_csize, g_root_id, g_vroot, g_vsize, nullptr,
-                        &nvalid, fg_cluster);
+                        &nvalid, fg_cluster, fg_pixel, fg_depth, row_k, wz);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -613,6 +647,7 @@ Locator::Locator(const rmr_locator_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg.de
     blk_count_.alloc(nblk);
     blk_offset_.alloc(nblk);
     parent_.alloc(mf);
+    fg_depth_.alloc(mf);
     csize_.alloc(mf);
     vroot_.alloc(mf);
     vsize_.alloc(mf);
@@ -701,6 +736,31 @@ void Locator::update(const float* xyz, int n, int stride_bytes, int mem) {
 }
 
 // locate.cpp:231-264
+// smallest singular value of a 3x3 matrix (closed-form eigenvalues of M^T M): lidar-frame distances
+// are at least this factor times camera-frame distances
+static double min_singular3(const float* m) {
+    double a[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            a[i][j] = 0;
+            for (int k = 0; k < 3; ++k) a[i][j] += (double)m[k * 3 + i] * m[k * 3 + j];
+        }
+    const double p1 = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    const double q = (a[0][0] + a[1][1] + a[2][2]) / 3.0;
+    const double p2 = (a[0][0] - q) * (a[0][0] - q) + (a[1][1] - q) * (a[1][1] - q) + (a[2][2] - q) * (a[2][2] - q) + 2 * p1;
+    if (p2 < 1e-30) return std::sqrt(std::max(q, 0.0));  // a multiple of the identity
+    const double p = std::sqrt(p2 / 6.0);
+    double b[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) b[i][j] = (a[i][j] - (i == j ? q : 0.0)) / p;
+    const double det = b[0][0] * (b[1][1] * b[2][2] - b[1][2] * b[2][1]) - b[0][1] * (b[1][0] * b[2][2] - b[1][2] * b[2][0]) +
+                       b[0][2] * (b[1][0] * b[2][1] - b[1][1] * b[2][0]);
+    const double r = std::min(1.0, std::max(-1.0, det / 2.0));
+    const double phi = std::acos(r) / 3.0;
+    const double e_min = q + 2.0 * p * std::cos(phi + 2.0943951023931953);
+    return std::sqrt(std::max(e_min, 0.0)) * 0.999;
+}
+
 void Locator::cluster() {
     ctx_.use();
     const int mf = cfg_.max_foreground;
@@ -710,15 +770,24 @@ void Locator::cluster() {
     ProfScope ps(ctx_.prof, stream_, "loc_cluster", 0, (double)npx_ * 8);
     fg_count<<<nblk, 256, 0, stream_>>>(diff_.p, npx_, blk_count_.p);
     fg_scan<<<1, 1024, 0, stream_>>>(blk_count_.p, nblk, blk_offset_.p, mf, counters_.p, cur.n_fg);
-    fg_compact<<<nblk, 256, 0, stream_>>>(prm_, diff_.p, npx_, blk_offset_.p, mf, cur.fg_pixel, cur.fg_xyz);
+    fg_compact<<<nblk, 256, 0, stream_>>>(prm_, diff_.p, npx_, blk_offset_.p, mf, cur.fg_pixel, cur.fg_xyz, fg_depth_.p);
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void*)cc_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * CC_LDS_MAX * 4);
+        (void)hipFuncSetAttribute((const void*)cc_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * CC_LDS_MAX * 4);
     });
     (void)gfg;
-    cc_fused<<<1, CC_THREADS, 8 * CC_LDS_MAX * sizeof(int), stream_>>>(
+    // rows two points closer than the tolerance can be apart, times the depth (see cc_block);
+    // only for a pinhole intrinsic whose image row depends on y alone
+    float row_k = 0.f;
+    const double s_min = min_singular3(prm_.R);  // 1 for a calibration (rigid) camera-to-lidar rotation
+    if (prm_.K[3] == 0.f && prm_.K[4] > 0.f && s_min > 1e-3) {
+        const float fy = prm_.K[4], cy = prm_.K[5], h_full = (float)prm_.hz / prm_.zoom;
+        const float t_max = std::max(std::fabs(cy), std::fabs(h_full - cy)) / fy;
+        row_k = (float)(prm_.zoom * fy * std::sqrt(prm_.tol2) / s_min * (1.f + t_max) * 1.001);
+    }
+    cc_fused<<<1, CC_THREADS, 9 * CC_LDS_MAX * sizeof(int), stream_>>>(
         counters_.p, cur.fg_xyz, prm_.tol2, prm_.min_cluster, prm_.max_cluster, parent_.p, csize_.p, root_id_.p,
-        vroot_.p, vsize_.p, cur.fg_cluster, cur.n_clusters);
+        vroot_.p, vsize_.p, cur.fg_cluster, cur.n_clusters, cur.fg_pixel, fg_depth_.p, row_k, prm_.wz);
     RMR_HIP(hipGetLastError());
 }
 

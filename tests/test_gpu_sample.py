@@ -82,3 +82,53 @@ def test_sample_radar_run_once_matches_oracle(tmp_path_factory, oracle):
                 assert np.max(np.abs(loc - loc_g)) <= 0.05  # same robot, sub-pixel rect change
     assert total_located >= 1
     radar.close()
+
+
+def test_run_batch_equals_separate_calls(tmp_path_factory):
+    """rmr_pipeline_run_batch (locate on a helper thread while detect runs, batched search) returns
+    what update / cluster / keep + detect_batch + per-frame search return."""
+    import ctypes as C
+
+    import rm_radar_amd as rmr
+    from rm_radar_amd import _lib
+    from rm_radar_amd import weights as W
+    d = tmp_path_factory.mktemp("rb_packs")
+    car, armor = str(d / "car.rmrw"), str(d / "armor.rmrw")
+    W.make_synthetic_pack(car, "m", 1, seed=1, cls_bias=-6.0)
+    W.make_synthetic_pack(armor, "m", 12, seed=2, cls_bias=-3.0)
+    nf, k, size = 3, 2, (640, 640)
+    rng = np.random.default_rng(5)
+    rects = [[(100, 300, 120, 90), (400, 200, 80, 120)] for _ in range(nf)]
+    images = [scenes.synthetic_image(70 + f) for f in range(nf)]
+    bg = scenes.make_cloud(rng, 30000, scenes.K640, scenes.SAMPLE_L2C, size)
+    clouds = [scenes.make_cloud(rng, 20000, scenes.K640, scenes.SAMPLE_L2C, size, [(r, 2000.0, 250) for r in rects[f]])
+              for f in range(nf)]
+    rd = rmr.RobotDetector(car, armor, size, 12, max_cars=k, opt_cars=k, max_frames=nf)
+    cap = rd.max_cars
+    out = []
+    for mode in ("native", "separate"):
+        loc = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), max_frames=nf)
+        loc.update(bg)
+        if mode == "native":
+            robots, counts = rmr.run_batch(rd, loc, images, clouds, rects)
+        else:
+            for f in range(nf):
+                loc.update(clouds[f]), loc.cluster(), loc.keep(f)
+            robots, counts = rd.detect_batch_raw(images, rects)
+            for f in range(nf):
+                if counts[f]:
+                    loc.search_raw(C.cast(C.addressof(robots) + f * cap * C.sizeof(_lib.Robot), C.POINTER(_lib.Robot)),
+                                   int(counts[f]), frame=f)
+        out.append([[rmr.Robot.from_c(robots[f * cap + i]) for i in range(counts[f])] for f in range(nf)])
+        loc.close()
+    located = 0
+    for fa, fb in zip(*out):
+        assert len(fa) == len(fb) and 1 <= len(fa) <= k  # same-label crops may be grouped into one robot
+        for a, b in zip(fa, fb):
+            assert (a.rect, a.label, a.location) == (b.rect, b.label, b.location)
+            located += a.location is not None
+    assert located >= 2
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.run_batch(rd, rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32)),
+                      images, clouds, rects)  # locator without kept-frame slots
+    rd.close()
