@@ -166,7 +166,7 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             RMR_HIP(hipMemsetAsync(dtiming.p, 0, 64, ctx.stream));
             a.timing = dtiming.p;
         }
-        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..: conv_direct tile
+        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
         } else if (tile >= 1000) {
@@ -185,6 +185,9 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             launch_conv_dma(ctx, ctx.stream, a, t);
             launch_conv_dma(ctx, ctx.stream, a, t);  // twice: the counters must re-arm themselves
             RMR_HIP(hipStreamSynchronize(ctx.stream));
+        } else if (tile == 500) {
+            if (!conv_stem_supported(a)) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: the stem kernel cannot run this layer");
+            launch_conv_stem(ctx, ctx.stream, a);
         } else if (tile >= 400) {
             if (!conv_direct_supported(a, tile - 400))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: direct tile %d cannot run this layer", tile - 400);

@@ -72,6 +72,9 @@ int conv_direct_num_tiles();
 ConvTile conv_direct_tile(int id);
 bool conv_direct_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_direct(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+// the network's first layer (conv_stem.hip): 3x3 / stride 2, 8 stored -> 48 channels, an HBM stream
+bool conv_stem_supported(const ConvArgs& a);
+void launch_conv_stem(DeviceCtx& ctx, hipStream_t stream, ConvArgs a);
 // picks the kernel family and tile for a layer (RMR_CONV=igemm|dma overrides) and launches it
 void launch_conv_auto(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a);
 

@@ -1,0 +1,186 @@
+// conv_stem.hip -- the first layer of YOLOv8m: 3x3 / stride 2 / pad 1, 3 (stored as 8) -> 48
+// channels, 640x640 -> 320x320.
+//
+// K is only 72 (9 taps x 8 stored channels) and the layer moves 16 B in and 24 B out per input
+// pixel: it is an HBM stream, not a GEMM (1.05 GB per 64-image chunk, 0.13 ms at 8 TB/s).  The
+// generic im2col kernel gathers every 16-byte tap separately and reaches 35 TFLOP/s (2.2 TB/s).
+// Here a workgroup owns an 8 x 32 output tile:
+//   * its 17 x 65 input patch (17.7 KB) is DMA'd into LDS once, lane-linear, out-of-image pixels
+//     arriving as zeros from the buffer bounds check (that is the padding);
+//   * a K step of the 16x16x32 MFMA is four taps: lane group kg reads tap 4 ks + kg of its
+//     pixel, one ds_read_b128 (8 stored channels) per lane; three K steps cover the nine taps, the
+//     three surplus tap slots meet zero weights;
+//   * the 48 x 96 filter sits in 36 VGPRs for the whole kernel;
+//   * results are staged in LDS and leave as 16-byte chunks, whole 96-byte pixels per six lanes.
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "conv_igemm.h"
+
+namespace rmr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ST_TH = 8, ST_TW = 32;                  // output tile
+constexpr int ST_PH = 2 * ST_TH + 1, ST_PW = 2 * ST_TW + 1;  // input patch (pixels)
+constexpr int ST_PATCH = ST_PH * ST_PW;               // 1105 pixels of 16 B
+constexpr int ST_DMA = (ST_PATCH + 63) / 64;          // 18 DMA instructions
+constexpr int ST_NI = (ST_DMA + 3) / 4;               // per wave
+constexpr int ST_PATCH_BYTES = ST_DMA * 1024;
+constexpr int ST_OUT_BYTES = ST_TH * ST_TW * 96;
+constexpr int ST_LDS = ST_PATCH_BYTES + ST_OUT_BYTES;
+
+__device__ __forceinline__ float silu_s(float v) { return v / (1.0f + __expf(-v)); }
+
+__device__ __forceinline__ void dma16s(u32x4 rsrc, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, kg = lane >> 4;
+
+    const int tiles_x = a.Wo / ST_TW, tiles_y = a.Ho / ST_TH;
+    const int img = blockIdx.x / (tiles_x * tiles_y);
+    const int t = blockIdx.x % (tiles_x * tiles_y);
+    const int oy0 = (t / tiles_x) * ST_TH, ox0 = (t % tiles_x) * ST_TW;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+
+    // ---- the input patch, lane-linear: LDS pixel id = row * ST_PW + col ------------------------
+    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
+                           sgpr(a.in_bytes), sgpr(0x00020000u)};
+#pragma unroll
+    for (int j = 0; j < ST_NI; ++j) {
+        const int q = wave + 4 * j;  // wave-uniform
+        if (q < ST_DMA) {
+            const int id = q * 64 + lane;
+            const int pr = id / ST_PW, pc = id - pr * ST_PW;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            const bool ok = id < ST_PATCH && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)((((img * a.H + iy) * a.W + ix) * a.in_cs + a.in_co) * 2) : 0xffffffffu;
+            dma16s(in_rsrc, sgpr(lds0 + q * 1024), off);
+        }
+    }
+
+    // ---- the filter: B fragments for 3 K steps x 3 channel tiles ------------------------------
+    half8 wreg[3][3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            wreg[ks][j] = *(const half8*)((const _Float16*)a.wt + (size_t)(j * 16 + frow) * a.Kp + ks * 32 + kg * 8);
+    const int cq = kg * 4;
+    float4 bias[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bias[j] = *(const float4*)(a.bias + j * 16 + cq);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- wave w: output rows 2w, 2w + 1 of the tile, two 16-pixel fragments each ----------------
+    floatx4 acc[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        int tap = 4 * ks + kg;
+        tap = tap < 9 ? tap : 8;  // surplus slots: zero weights, any finite pixel
+        const int kh = tap / 3, kw = tap - kh * 3;
+        half8 xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 2 * wave + (i >> 1), c = (i & 1) * 16 + frow;  // output pixel within the tile
+            xf[i] = *(const half8*)(smem + ((2 * r + kh) * ST_PW + 2 * c + kw) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][j], xf[i], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: bias + SiLU, f16, through LDS so that stores are whole pixels ----------------
+    unsigned char* const stage = smem + ST_PATCH_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 2 * wave + (i >> 1), c = (i & 1) * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
+                          acc[i][j][3] + bias[j].w};
+            if (a.act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_s(v[e]);
+            }
+            if (a.out32) {
+                const long m = ((long)img * a.Ho + oy0 + r) * a.Wo + ox0 + c;
+                *(float4*)(a.out32 + m * a.out_cs + a.out_co + j * 16 + cq) = make_float4(v[0], v[1], v[2], v[3]);
+                continue;
+            }
+            union {
+                uint2 u;
+                _Float16 h[4];
+            } o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.h[e] = (_Float16)v[e];
+            *(uint2*)(stage + (r * ST_TW + c) * 96 + (j * 16 + cq) * 2) = o.u;
+        }
+    }
+    if (a.out32) return;
+    __syncthreads();
+    for (int ch = tid; ch < ST_TH * ST_TW * 6; ch += 256) {
+        const int p = ch / 6, part = ch - p * 6;
+        const int r = p / ST_TW, c = p - r * ST_TW;
+        const long m = ((long)img * a.Ho + oy0 + r) * a.Wo + ox0 + c;
+        *(u32x4*)((unsigned char*)a.out + (m * a.out_cs + a.out_co) * 2 + part * 16) = *(const u32x4*)(stage + ch * 16);
+    }
+}
+
+}  // namespace
+
+bool conv_stem_supported(const ConvArgs& a) {
+    return a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.Cin == 8 && a.Cout_pad == 48 && a.Kp >= 96 &&
+           a.Wo % ST_TW == 0 && a.Ho % ST_TH == 0 && a.Ho == a.H / 2 && a.Wo == a.W / 2 && a.H % 2 == 0 && a.W % 2 == 0 &&
+           !a.res && a.in_bytes != 0;
+}
+
+void launch_conv_stem(DeviceCtx& ctx, hipStream_t stream, ConvArgs a) {
+    if (!conv_stem_supported(a)) fail(RMR_ERR_LOGIC, "conv_stem: layer not supported");
+    if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8) fail(RMR_ERR_LOGIC, "conv_stem: misaligned view");
+    if (a.in_bytes > 0xf0000000ull) fail(RMR_ERR_LOGIC, "conv_stem: input view larger than 3.75 GiB");
+    const int grid = a.N * (a.Ho / ST_TH) * (a.Wo / ST_TW);
+    const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
+    const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
+    static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
+    static std::mutex name_mu;
+    static std::map<std::string, std::string> names;
+    const char* pname = "conv_igemm_f16";
+    if (per_layer && ctx.prof.on) {
+        char buf[48];
+        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d stem", a.M, a.Cout_pad, a.K, a.KH, a.stride);
+        std::lock_guard<std::mutex> lk(name_mu);
+        pname = names.emplace(buf, buf).first->second.c_str();
+    }
+    ProfScope ps(ctx.prof, stream, pname, flops, bytes);
+    conv_stem_kernel<<<grid, 256, ST_LDS, stream>>>(a);
+    RMR_HIP(hipGetLastError());
+}
+
+}  // namespace rmr

@@ -187,6 +187,20 @@ def test_conv_direct_every_tile(rmr):
                    False, tile=400)  # 48 output channels on a 96-wide tile
 
 
+def test_conv_stem(rmr):
+    # conv_stem.hip (id 500): 3x3 / stride 2, 3 -> 48 channels; the input patch of an 8 x 32 output
+    # tile is staged once, image borders arrive as zeros from the buffer bounds check
+    run_case(rmr, 2, 64, 128, 3, 48, 3, 2, True, False, tile=500, seed=150)    # 4 x 2 tiles per image, every border
+    run_case(rmr, 1, 16, 64, 3, 48, 3, 2, False, False, tile=500, seed=151)    # one tile, no activation
+    run_case(rmr, 1, 160, 192, 3, 41, 3, 2, True, False, tile=500, seed=152)   # 41 channels padded to 48
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 16, 48, 3), np.float32), np.zeros((48, 3, 3, 3), np.float32), None, 2, 1,
+                   False, tile=500)  # output width 24 is not a multiple of the 32-pixel tile
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 16, 64, 3), np.float32), np.zeros((48, 3, 3, 3), np.float32), None, 1, 1,
+                   False, tile=500)  # stride 1
+
+
 def test_conv_matches_c_oracle(rmr, oracle):
     # the plain-C direct convolution (oracle/rmr_oracle.c) agrees with both
     rng = np.random.default_rng(5)
