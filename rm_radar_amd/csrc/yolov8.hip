@@ -204,7 +204,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
         fail(RMR_ERR_INVALID_ARGUMENT, "weight pack '%s' has %d classes, Detector was given %d", pack_path.c_str(), nc_, expect_nc);
     if (p.reg_max != 16) fail(RMR_ERR_RUNTIME, "only reg_max = 16 is supported");
 
-    int chunk = 64;
+    int chunk = 256;
     if (const char* e = std::getenv("RMR_CHUNK")) chunk = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RMR_AUTOTUNE")) autotune_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("RMR_GRAPH")) graph_max_batch_ = atoi(e);
