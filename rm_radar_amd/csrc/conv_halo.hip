@@ -337,6 +337,8 @@ const HaloTile kHaloTiles[] = {
     HTILE_T(8, 2, 2, 6, 4, 1),   // 28: 256 x 192
     HTILE_T(8, 2, 2, 3, 6, 1),   // 29: 256 x 96
     HTILE_T(8, 2, 2, 9, 4, 1),   // 30: 256 x 288
+    HTILE_T(8, 2, 4, 3, 6, 1),   // 31: 512 x 96
+    HTILE_T(8, 2, 4, 3, 16, 3),  // 32: 512 x 96, one barrier per filter row
 };
 constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
 
