@@ -79,6 +79,25 @@ def test_network_output_matches_oracle(rmr, oracle, packs, refs, images, which, 
     det.close()
 
 
+@pytest.mark.parametrize("n", [64, 256])
+def test_large_batch_uses_the_same_network(rmr, packs, refs, images, oracle, n):
+    """The kernels the autotuner picks for the throughput shapes (64 images per launch: wide halo
+    tiles, the weights-stationary and first-layer kernels, 8-wave DMA tiles) are only reached by
+    large batches (256 = one full chunk of the armor stage).  Slots filled with the three test
+    images must reproduce the CPU oracle's head tensor in every slot, to the same tolerance as a
+    small batch."""
+    det = rmr.Detector(packs[1], 12, (2592, 2048), n, conf_thresh=0.5)
+    batch = [images[i % 3] for i in range(n)]
+    got, _ = det.infer(batch)
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    want = refs["armor"][1].forward(blobs)  # f16-emulating oracle
+    for i in range(n):
+        _check_head(got[i:i + 1], want[i % 3:i % 3 + 1], 2.0, 1e-2)
+    # slots holding the same image went through the same kernels: bit-identical
+    assert np.array_equal(got[0], got[3]) and np.array_equal(got[1], got[n - 3])
+    det.close()
+
+
 def test_detect_matches_oracle_postprocess(rmr, oracle, packs, refs, images):
     det = rmr.Detector(packs[0], 1, (2592, 2048), 4)
     dets = det.detect(images)
