@@ -205,7 +205,9 @@ def main():
         dt = time.perf_counter() - t0
         stats = {}
     else:
-        with rmr.profile(local) as prof:
+        # events only around the convolution launches (the roofline kernel family): events on every
+        # launch of every stream cost the step 3 % (per-kernel times of the rest: profiles/*kernel_stats*)
+        with rmr.profile(local, flops_only=True) as prof:
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 block, counts = step()

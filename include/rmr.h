@@ -305,6 +305,8 @@ typedef struct {
     double bytes;  /* algorithmic HBM bytes summed over the launches */
 } rmr_kernel_stat;
 
+/* on: 0 off, 1 every launch, 2 only the launches that declare FLOPs (the convolution family: what
+ * the roofline of bench.py needs, at a third of the event records) */
 rmr_status rmr_profile_enable(int device, int on);
 rmr_status rmr_profile_reset(int device);
 /* resolves pending events (synchronises), writes up to cap entries, *n = entries available */

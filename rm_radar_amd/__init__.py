@@ -731,12 +731,13 @@ class Tracker:
 class profile:
     """HIP-event timing of the library's own launches (on the streams they run on)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, flops_only=False):
         self.device = device
+        self.level = 2 if flops_only else 1  # 2: only launches that declare FLOPs (the conv family)
 
     def __enter__(self):
         check(lib().rmr_profile_reset(self.device))
-        check(lib().rmr_profile_enable(self.device, 1))
+        check(lib().rmr_profile_enable(self.device, self.level))
         return self
 
     def __exit__(self, *exc):

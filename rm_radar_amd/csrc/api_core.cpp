@@ -302,7 +302,10 @@ int rmr_locator_num_clusters(rmr_locator* loc) {
 // ---- profiling ---------------------------------------------------------------------------
 
 rmr_status rmr_profile_enable(int device, int on) {
-    return guarded([&] { device_ctx(device).prof.on = on != 0; });
+    return guarded([&] {
+        if (on < 0 || on > 2) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_profile_enable: level %d", on);
+        device_ctx(device).prof.on = on;
+    });
 }
 rmr_status rmr_profile_reset(int device) {
     return guarded([&] { device_ctx(device).prof.reset(); });

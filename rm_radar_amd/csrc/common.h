@@ -125,7 +125,7 @@ struct ProfEntry {
 };
 
 struct Profiler {
-    bool on = false;
+    int on = 0;  // 0 off, 1 every launch, 2 only launches that declare FLOPs (the convolution family)
     std::mutex mu;
     struct Pending {
         hipEvent_t a, b;
@@ -149,7 +149,7 @@ struct ProfScope {
     hipStream_t s;
     Profiler::Pending rec{};
     ProfScope(Profiler& prof, hipStream_t stream, const char* name, double flops = 0, double bytes = 0)
-        : p(prof.on ? &prof : nullptr), s(stream) {
+        : p(prof.on == 1 || (prof.on == 2 && flops > 0) ? &prof : nullptr), s(stream) {
         if (p) {
             rec = Profiler::Pending{p->get_event(), p->get_event(), name, flops, bytes};
             (void)hipEventRecord(rec.a, s);

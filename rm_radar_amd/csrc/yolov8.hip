@@ -385,8 +385,8 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     hipEvent_t e0, e1;
     RMR_HIP(hipEventCreate(&e0));
     RMR_HIP(hipEventCreate(&e1));
-    const bool prof_was_on = ctx_.prof.on;
-    ctx_.prof.on = false;
+    const int prof_was_on = ctx_.prof.on;
+    ctx_.prof.on = 0;
     int best = cands.front();
     float best_ms = 1e30f;
     static const bool verbose = std::getenv("RMR_TUNE_VERBOSE") != nullptr;
