@@ -33,7 +33,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// v * rcp(1 + e^-v): the hardware reciprocal (1 ulp) instead of an IEEE division -- the epilogue's VALU
+// work is not small beside a short K loop (48 values per lane per tile)
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // 16 bytes per lane, global -> LDS.  m0 = wave-uniform LDS byte address; lane l lands at m0 + 16 l.
 __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff) {

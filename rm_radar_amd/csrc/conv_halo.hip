@@ -43,7 +43,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 
-__device__ __forceinline__ float silu_h(float v) { return v / (1.0f + __expf(-v)); }
+// v * rcp(1 + e^-v): the hardware reciprocal (1 ulp) instead of an IEEE division -- the epilogue's VALU
+// work is not small beside a short K loop (48 values per lane per tile)
+__device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ void dma16h(u32x4 rsrc, unsigned lds_addr, unsigned voff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
@@ -125,6 +127,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     const int ch_in_chunk = lchunk * 8;
 
     const unsigned scratch = sgpr(lds0 + b_base + BSTAGES * B_STAGE_BYTES);  // idle slots land here
+    const int zero_off = b_base + BSTAGES * B_STAGE_BYTES + 1024;            // 16 zero bytes: what padding taps read
+    if (tid == 0) *(u32x4*)(smem + zero_off) = u32x4{0, 0, 0, 0};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave reaches the first barrier
 
     // Issues the DMA instructions that ride on slice sl = cc * SPC + g: the weights of the slice
     // BSTAGES - 1 ahead and one SPC-th of the NEXT chunk's input range.
@@ -231,11 +236,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
             half8 xf[MREP], wf[NREP];
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
+                // a tap outside the image reads the zero block instead: ONE select on the address
+                // before the read, not four on the data between the read and the MFMA
                 const int row = a_row[i] + shift;
-                half8 v = *(const half8*)(smem + a_buf + row * 64 + ((kg ^ hkey(row)) * 16));
+                const int at = a_buf + row * 64 + ((kg ^ hkey(row)) * 16);
                 const bool ok = (a_mask[i] >> t) & 1u;
-                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                xf[i] = ok ? v : z;
+                xf[i] = *(const half8*)(smem + (ok ? at : zero_off));
             }
 #pragma unroll
             for (int j = 0; j < NREP; ++j) wf[j] = *(const half8*)(bp + j * 16 * 64);
@@ -345,7 +351,7 @@ constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
 int halo_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
 int halo_lds_bytes(const HaloTile& t, int W) {
     const int stages = t.tps == 9 ? 2 : 3;
-    return 2 * halo_rows(t.bm, W) * 64 + stages * t.bn * 64 * t.tps + 1024;  // + one scratch KiB for idle slots
+    return 2 * halo_rows(t.bm, W) * 64 + stages * t.bn * 64 * t.tps + 1024 + 64;  // + one scratch KiB for idle slots, + the zero block
 }
 
 }  // namespace

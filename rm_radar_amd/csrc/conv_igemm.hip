@@ -33,7 +33,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 
-__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+// v * rcp(1 + e^-v): the hardware reciprocal (1 ulp) instead of an IEEE division -- the epilogue's VALU
+// work is not small beside a short K loop (48 values per lane per tile)
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 template <int WM, int WN, int MREP, int NREP, int BK, bool UT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {

@@ -36,7 +36,9 @@ constexpr int ST_PATCH_BYTES = ST_DMA * 1024;
 constexpr int ST_OUT_BYTES = ST_TH * ST_TW * 96;
 constexpr int ST_LDS = ST_PATCH_BYTES + ST_OUT_BYTES;
 
-__device__ __forceinline__ float silu_s(float v) { return v / (1.0f + __expf(-v)); }
+// v * rcp(1 + e^-v): the hardware reciprocal (1 ulp) instead of an IEEE division -- the epilogue's VALU
+// work is not small beside a short K loop (48 values per lane per tile)
+__device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ void dma16s(u32x4 rsrc, unsigned lds_addr, unsigned voff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
