@@ -198,22 +198,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     const int kg = lane >> 4;
     int a_row[MREP];         // LDS row of this lane's pixel (centre tap) per fragment
     unsigned a_mask[MREP];   // valid-tap bits of this lane's pixel per fragment
+    // One division for the wave's first pixel, then 16-pixel steps (the setup runs once per tile and
+    // a 27-slice K loop is short: two divisions and nine tests per fragment were a third of its VALU
+    // work).  Valid taps = (rows kh with 0 <= y + kh - 1 < H) x (columns kw likewise): bit 3 kh + kw.
+    {
+        const int q0 = wm * MREP * 16 + frow;
+        int x = (m0 + q0) % W;
+        int y = ((m0 + q0) / W) % a.H;
 #pragma unroll
-    for (int i = 0; i < MREP; ++i) {
-        const int q = (wm * MREP + i) * 16 + frow;  // pixel within the tile
-        a_row[i] = q + W + 1;
-        const int m = m0 + q;
-        unsigned mask = 0;
-        if (m < a.M) {
-            const int x = m % W;
-            const int y = (m / W) % a.H;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)W) mask |= 1u << t;
+        for (int i = 0; i < MREP; ++i) {
+            a_row[i] = q0 + i * 16 + W + 1;
+            const unsigned rows = (y > 0 ? 0x007u : 0u) | 0x038u | (y < a.H - 1 ? 0x1c0u : 0u);
+            const unsigned cols = (x > 0 ? 0x049u : 0u) | 0x092u | (x < W - 1 ? 0x124u : 0u);
+            a_mask[i] = (m0 + q0 + i * 16 < a.M) ? (rows & cols) : 0u;
+            x += 16;
+            while (x >= W) {  // W >= 1: a few steps at most for tiny maps
+                x -= W;
+                if (++y == a.H) y = 0;
             }
         }
-        a_mask[i] = mask;
     }
     const int b_frag = b_base + (wn * NREP * 16 + frow) * 64 + ((kg ^ hkey(frow)) * 16);
 
