@@ -160,6 +160,7 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         a.in_bytes = (unsigned)(hx.size() * sizeof(__half));
         a.wt_bytes = (unsigned)(packed.size() * sizeof(__half));
         DevBuf<long long> dtiming;
+        // per-phase cycle stamps of conv_dma / conv_direct: needs a build with -DRMR_CONV_TIMING_BUILD=1
         const bool want_timing = std::getenv("RMR_CONV_TIMING") != nullptr;
         if (want_timing) {
             dtiming.alloc(8);

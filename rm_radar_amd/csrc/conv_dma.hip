@@ -24,6 +24,10 @@
 
 #include "conv_igemm.h"
 
+#ifndef RMR_CONV_TIMING_BUILD
+#define RMR_CONV_TIMING_BUILD 0
+#endif
+
 namespace rmr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -161,6 +165,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
         k_kh = t / a.KW;
     }
 
+    // slot kinds of this wave (wave-uniform, loop-invariant)
+    unsigned k_a[NI];
+    u32x4 k_rsrc[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const bool is_a = (wave + NW * j) * RPD < BM;
+        k_a[j] = is_a ? 0xffffffffu : 0u;
+        k_rsrc[j] = u32x4{is_a ? in_rsrc[0] : wt_rsrc[0], is_a ? in_rsrc[1] : wt_rsrc[1], is_a ? in_rsrc[2] : wt_rsrc[2],
+                          in_rsrc[3]};
+    }
+
     auto issue = [&](int kt, int stage) {
         const bool live = kt < nk;  // slots past the last slice are issued as no-ops (constant vmcnt)
         int delta[HALVES];
@@ -181,21 +196,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
         const int my_delta = HALVES == 2 && lhalf ? delta[HALVES - 1] : delta[0];
         const unsigned my_bit = HALVES == 2 && lhalf ? tap_bit[HALVES - 1] : tap_bit[0];
         const int wdelta = kt * BK * 2;
+        const unsigned dead = live ? 0u : 0xffffffffu;  // wave-uniform
+        // straight-line: both candidate offsets are one add each, the slot kind (k_a, loop-invariant)
+        // picks one with mask arithmetic.  Written with branches this was ~100 scalar instructions and
+        // a dozen jumps per slice -- 15 SALU per MFMA on the 256 x 96 tile.
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int blk = wave + NW * j;  // wave-uniform
-            const bool is_a = blk * RPD < BM;
-            unsigned off = OOB;
-            if (is_a) {
-                if (s_mask[j] & my_bit) off = (unsigned)(s_off[j] + my_delta);
-            } else if (live && s_mask[j]) {
-                off = (unsigned)(s_off[j] + wdelta);
-            }
+            const unsigned off_a = (unsigned)(s_off[j] + my_delta) | ((s_mask[j] & my_bit) ? 0u : 0xffffffffu);
+            const unsigned off_w = (unsigned)(s_off[j] + wdelta) | dead | (s_mask[j] ? 0u : 0xffffffffu);
+            const unsigned off = (k_a[j] & off_a) | (~k_a[j] & off_w);  // all ones = out of range = zero fill / no-op
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_BYTES + blk * 1024));
-            if (is_a)
-                dma16(in_rsrc, dst, off);
-            else
-                dma16(wt_rsrc, dst, off);
+            dma16(k_rsrc[j], dst, off);
         }
     };
 
@@ -216,7 +228,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
     const unsigned char* b_frag = smem + (BM + wn * NREP * 16 + frow) * RB;
 
     // debug timing (a.timing != null): cycles spent by one wave in each phase of the K loop
+    // (compiled in only with -DRMR_CONV_TIMING_BUILD=1: the per-slice stamps and their selects cost
+    // every launch ~15 scalar instructions per MFMA otherwise)
+#if RMR_CONV_TIMING_BUILD
     const bool timed = a.timing != nullptr && blockIdx.x == gridDim.x / 2 && wave == 1;
+#else
+    constexpr bool timed = false;
+#endif
     long long t_wait = 0, t_bar = 0, t_issue = 0, t_read = 0, t_mfma = 0;
     auto now = [&]() -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
 
