@@ -30,16 +30,44 @@ extern "C" rmr_status rmr_pipeline_run_batch(rmr_robot_detector* rd, rmr_locator
                 locate_error = std::current_exception();
             }
         });
-        // thread B (the caller): two-stage detect over all frames
+        // thread B (the caller): two-stage detect over all frames.  As soon as the car boxes are
+        // known the search is enqueued behind the locate work -- it needs the boxes only -- so it runs
+        // under the armor stage instead of after it.
+        const int stride = cap;
+        std::vector<rmr_robot> car_robots((size_t)n_frames * stride);
+        std::vector<int> car_counts(n_frames, 0), car_index((size_t)n_frames * cap, -1);
+        bool searching = false;
+        auto after_cars = [&](const std::vector<std::vector<rmr_detection>>& cars) {
+            locate.join();
+            if (locate_error) return;
+            for (int f = 0; f < n_frames; ++f) {
+                car_counts[f] = std::min((int)cars[f].size(), stride);
+                for (int i = 0; i < car_counts[f]; ++i) {
+                    rmr_robot& r = car_robots[(size_t)f * stride + i];
+                    r.rect[0] = cars[f][i].x, r.rect[1] = cars[f][i].y, r.rect[2] = cars[f][i].width, r.rect[3] = cars[f][i].height;
+                }
+            }
+            loc->impl.search_batch_begin(car_robots.data(), car_counts.data(), n_frames, stride);
+            searching = true;
+        };
         std::exception_ptr detect_error;
         try {
-            rd->impl.detect_batch(imgs, n_frames, forced_crops, forced_per_frame, out, n_out, cap);
+            rd->impl.detect_batch(imgs, n_frames, forced_crops, forced_per_frame, out, n_out, cap, after_cars,
+                                  car_index.data());
         } catch (...) {
             detect_error = std::current_exception();
         }
-        locate.join();
+        if (locate.joinable()) locate.join();
         if (detect_error) std::rethrow_exception(detect_error);
         if (locate_error) std::rethrow_exception(locate_error);
-        loc->impl.search_batch(out, n_out, n_frames, cap);
+        if (searching) loc->impl.search_batch_end(car_robots.data(), car_counts.data(), n_frames, stride);
+        for (int f = 0; f < n_frames; ++f)
+            for (int i = 0; i < std::min(n_out[f], cap); ++i) {
+                const int c = car_index[(size_t)f * cap + i];
+                if (c < 0 || c >= car_counts[f]) continue;  // a car beyond the caller's cap: not searched
+                const rmr_robot& src = car_robots[(size_t)f * stride + c];
+                rmr_robot& dst = out[(size_t)f * cap + i];
+                if (src.has_location) dst.has_location = 1, std::copy(src.location, src.location + 3, dst.location);
+            }
     });
 }

@@ -225,7 +225,8 @@ RobotDetector::RobotDetector(const rmr_robot_detector_cfg& cfg)
 
 // RobotDetector::detect (detector.cpp:413-455) for n_frames independent frames
 void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int* forced_crops, int forced_per_frame,
-                                 rmr_robot* out, int* n_out, int cap) {
+                                 rmr_robot* out, int* n_out, int cap, const AfterCars& after_cars,
+                                 int* car_index_out) {
     if (n_frames <= 0 || !imgs || !out || !n_out || cap <= 0)
         fail(RMR_ERR_INVALID_ARGUMENT, "RobotDetector::detect: bad arguments");
     if (n_frames > cfg_.max_frames)
@@ -253,11 +254,14 @@ void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int*
         }
     }
 
+    for (int f = 0; f < n_frames; ++f)
+        if ((int)cars[f].size() > cfg_.max_cars) cars[f].resize(cfg_.max_cars);  // Q10d
+    if (after_cars) after_cars(cars);
+
     // stage 2: one armor batch over every car crop of every frame (detector.cpp:417-425)
     descs.clear();
     std::vector<int> slot_of;  // per (frame, car): index into the armor batch or -1
     for (int f = 0; f < n_frames; ++f) {
-        if ((int)cars[f].size() > cfg_.max_cars) cars[f].resize(cfg_.max_cars);  // Q10d
         for (const rmr_detection& c : cars[f]) {
             // cv::Rect(x, y, w, h) from floats truncates (detector.cpp:420-421)
             const int x = (int)c.x, y = (int)c.y, w = (int)c.width, h = (int)c.height;
@@ -289,10 +293,15 @@ void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int*
             static const std::vector<rmr_detection> none;
             const auto& a = s >= 0 ? armors[s] : none;
             robot_set_detection(robots[i], cars[f][i], a.data(), (int)a.size());
+            robots[i].track_state = (int)i + 1;  // tag: which car (grouping copies robots whole)
         }
-        const auto grouped = group_robots(robots.data(), (int)robots.size(), cfg_.iou_thresh);
+        auto grouped = group_robots(robots.data(), (int)robots.size(), cfg_.iou_thresh);
         n_out[f] = (int)grouped.size();
         const int m = std::min(n_out[f], cap);
+        for (int i = 0; i < m; ++i) {
+            if (car_index_out) car_index_out[(size_t)f * cap + i] = grouped[i].track_state - 1;
+            grouped[i].track_state = RMR_TRACK_NONE;
+        }
         std::copy(grouped.begin(), grouped.begin() + m, out + (size_t)f * cap);
         over |= n_out[f] > cap;
     }

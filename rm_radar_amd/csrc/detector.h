@@ -1,5 +1,6 @@
 // detector.h -- Detector and RobotDetector back ends (src/detect/detector.h:84-190).
 #pragma once
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -68,8 +69,14 @@ class RobotDetector {
    public:
     explicit RobotDetector(const rmr_robot_detector_cfg& cfg);
     // RobotDetector::detect (detector.cpp:413-455), batched over frames
+    // after_cars (optional) runs as soon as stage 1 is known -- the car boxes per frame, before the
+    // armor stage is enqueued; car_index_out (optional, [n_frames][cap]) names the car each output
+    // robot came from.  Together they let the caller start work that only needs the car boxes
+    // (Locator::search) while the armor stage runs.
+    using AfterCars = std::function<void(const std::vector<std::vector<rmr_detection>>&)>;
     void detect_batch(const rmr_image* imgs, int n_frames, const int* forced_crops, int forced_per_frame,
-                      rmr_robot* out, int* n_out, int cap);
+                      rmr_robot* out, int* n_out, int cap, const AfterCars& after_cars = nullptr,
+                      int* car_index_out = nullptr);
 
    private:
     rmr_robot_detector_cfg cfg_;

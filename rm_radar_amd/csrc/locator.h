@@ -38,6 +38,9 @@ class Locator {
     // kept frames 0 .. n_frames-1 in one pass: robots[f * cap + i], i < counts[f]; one upload of the
     // rects, one launch per frame, one download, ONE synchronisation
     void search_batch(rmr_robot* robots, const int* counts, int n_frames, int cap);
+    // the same in two halves: enqueue (no synchronisation) / wait and write the locations
+    void search_batch_begin(const rmr_robot* robots, const int* counts, int n_frames, int cap);
+    void search_batch_end(rmr_robot* robots, const int* counts, int n_frames, int cap);
     void keep(int frame);
 
     int width() const { return prm_.wz; }
@@ -88,6 +91,7 @@ class Locator {
     DevBuf<float> loc_dev_;
     PinnedBuf<int> rects_pin_;
     PinnedBuf<float> loc_pin_;
+    PinnedBuf<int> search_flags_;  // capacity-overflow flag read back with a batched search
 };
 
 // OpenCV-compatible small inverses (cv::Matx::inv, DECOMP_LU) used by the ctor

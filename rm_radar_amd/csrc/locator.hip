@@ -865,20 +865,31 @@ void Locator::search(rmr_robot* robots, int n, int slot) {
 }
 
 void Locator::search_batch(rmr_robot* robots, const int* counts, int n_frames, int cap) {
-    ctx_.use();
-    if (n_frames <= 0) return;
-    if (!robots || !counts || cap <= 0 || n_frames > cfg_.max_frames)
-        fail(RMR_ERR_INVALID_ARGUMENT, "Locator::search_batch: bad arguments (frames %d of %d kept slots)", n_frames, cfg_.max_frames);
+    search_batch_begin(robots, counts, n_frames, cap);
+    search_batch_end(robots, counts, n_frames, cap);
+}
+
+static int checked_total(const rmr_robot* robots, const int* counts, int n_frames, int cap, int max_frames) {
+    if (!robots || !counts || cap <= 0 || n_frames > max_frames)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator::search_batch: bad arguments (frames %d of %d kept slots)", n_frames, max_frames);
     int total = 0;
     for (int f = 0; f < n_frames; ++f) {
         if (counts[f] < 0 || counts[f] > cap) fail(RMR_ERR_INVALID_ARGUMENT, "Locator::search_batch: counts[%d] = %d", f, counts[f]);
         total += counts[f];
     }
+    return total;
+}
+
+void Locator::search_batch_begin(const rmr_robot* robots, const int* counts, int n_frames, int cap) {
+    ctx_.use();
+    if (n_frames <= 0) return;
+    const int total = checked_total(robots, counts, n_frames, cap, cfg_.max_frames);
     if (total == 0) return;
     rects_pin_.ensure((size_t)4 * total);
     loc_pin_.ensure((size_t)4 * total);
     rects_dev_.ensure((size_t)4 * total);
     loc_dev_.ensure((size_t)4 * total);
+    search_flags_.ensure(2);
     int at = 0;
     for (int f = 0; f < n_frames; ++f)
         for (int i = 0; i < counts[f]; ++i, ++at) {
@@ -900,10 +911,17 @@ void Locator::search_batch(rmr_robot* robots, const int* counts, int n_frames, i
         at += counts[f];
     }
     RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * total, hipMemcpyDeviceToHost, stream_));
-    int flags[2] = {0, 0};
-    RMR_HIP(hipMemcpyAsync(flags, counters_.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    search_flags_.p[0] = 0;
+    RMR_HIP(hipMemcpyAsync(search_flags_.p, counters_.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+}
+
+void Locator::search_batch_end(rmr_robot* robots, const int* counts, int n_frames, int cap) {
+    ctx_.use();
+    if (n_frames <= 0) return;
+    const int total = checked_total(robots, counts, n_frames, cap, cfg_.max_frames);
+    if (total == 0) return;
     RMR_HIP(hipStreamSynchronize(stream_));
-    at = 0;
+    int at = 0;
     for (int f = 0; f < n_frames; ++f)
         for (int i = 0; i < counts[f]; ++i, ++at) {
             const float* o = loc_pin_.p + 4 * at;
@@ -913,7 +931,7 @@ void Locator::search_batch(rmr_robot* robots, const int* counts, int n_frames, i
                 r.location[0] = o[1], r.location[1] = o[2], r.location[2] = o[3];
             }
         }
-    if (flags[0]) fail(RMR_ERR_CAPACITY, "Locator: foreground exceeded max_foreground=%d points", cfg_.max_foreground);
+    if (search_flags_.p[0]) fail(RMR_ERR_CAPACITY, "Locator: foreground exceeded max_foreground=%d points", cfg_.max_foreground);
 }
 
 float* Locator::image_ptr(int which) {
