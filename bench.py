@@ -273,15 +273,13 @@ def main():
         rdet.close()
         loc.close()
         r1 = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1), device=local)
-        l1 = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=local)
+        l1 = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=local,
+                         max_frames=1)
         lat = []
         for i in range(220):  # 20 warm-up + 200 timed frames
             f = i % B
             t0 = time.perf_counter()
-            l1.update(clouds[f])
-            l1.cluster()
-            rb = r1.detect_batch([images[f]], forced_crops=[rects[f]])[0]
-            l1.search(rb)
+            rmr.run_batch(r1, l1, [images[f]], [clouds[f]], [rects[f]])  # the same native call, one frame
             lat.append((time.perf_counter() - t0) * 1e3)
         lat = np.array(lat[20:])
         result["p50_ms_batch1"] = round(float(np.percentile(lat, 50)), 3)

@@ -19,7 +19,7 @@ extern "C" rmr_status rmr_pipeline_run_batch(rmr_robot_detector* rd, rmr_locator
         // thread A: the Locator carries temporal state, so its frames go in stream order; each
         // frame's foreground list is kept in slot f for the batched search
         std::exception_ptr locate_error;
-        std::thread locate([&] {
+        auto locate_all = [&] {
             try {
                 for (int f = 0; f < n_frames; ++f) {
                     loc->impl.update(clouds[f], n_points[f], stride_bytes, mem);
@@ -29,7 +29,12 @@ extern "C" rmr_status rmr_pipeline_run_batch(rmr_robot_detector* rd, rmr_locator
             } catch (...) {
                 locate_error = std::current_exception();
             }
-        });
+        };
+        std::thread locate;
+        if (n_frames > 1)
+            locate = std::thread(locate_all);
+        else
+            locate_all();  // one frame: a few launches, cheaper to enqueue here than to start a thread
         // thread B (the caller): two-stage detect over all frames.  As soon as the car boxes are
         // known the search is enqueued behind the locate work -- it needs the boxes only -- so it runs
         // under the armor stage instead of after it.
@@ -38,7 +43,7 @@ extern "C" rmr_status rmr_pipeline_run_batch(rmr_robot_detector* rd, rmr_locator
         std::vector<int> car_counts(n_frames, 0), car_index((size_t)n_frames * cap, -1);
         bool searching = false;
         auto after_cars = [&](const std::vector<std::vector<rmr_detection>>& cars) {
-            locate.join();
+            if (locate.joinable()) locate.join();
             if (locate_error) return;
             for (int f = 0; f < n_frames; ++f) {
                 car_counts[f] = std::min((int)cars[f].size(), stride);
