@@ -132,3 +132,26 @@ def test_run_batch_equals_separate_calls(tmp_path_factory):
         rmr.run_batch(rd, rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32)),
                       images, clouds, rects)  # locator without kept-frame slots
     rd.close()
+
+
+def test_headless_cli_runs_the_reference_sample_layout(tmp_path, capsys):
+    """python -m rm_radar_amd.sample on a folder laid out like the reference's assets/ and models/
+    (samples/main.cpp:24-99): images/<i>, clouds/<i>.pcd, background.pcd, 100 ms timestamps."""
+    from rm_radar_amd import assets, sample
+    from rm_radar_amd import weights as W
+    models, ad = tmp_path / "models", tmp_path / "assets"
+    (ad / "images").mkdir(parents=True), (ad / "clouds").mkdir(), models.mkdir()
+    W.make_synthetic_pack(str(models / "car.rmrw"), "m", 1, seed=1, cls_bias=-5.0)
+    W.make_synthetic_pack(str(models / "armor.rmrw"), "m", 12, seed=2, cls_bias=-3.0)
+    data = np.load(os.path.join(os.path.dirname(__file__), "golden", "assets_clouds.npz"))
+    rng = np.random.default_rng(3)
+    assets.write_pcd(ad / "clouds" / "background.pcd",
+                     scenes.make_cloud(rng, 40000, scenes.SAMPLE_K, scenes.SAMPLE_L2C, scenes.SAMPLE_SIZE)[:, :3], binary=True)
+    for i in range(2):
+        np.save(ad / "images" / f"{i}.npy", netutil.test_image(50 + i, *scenes.SAMPLE_SIZE))
+        assets.write_pcd(ad / "clouds" / f"{i}.pcd", data[f"cloud{i}"].astype(np.float32))
+    assert sample.main(["--models", str(models), "--assets", str(ad), "--frames", "2"]) == 0
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith("frame 0: ") and any(l.startswith("frame 1: ") for l in out)
+    with pytest.raises(FileNotFoundError):
+        sample.main(["--models", str(models), "--assets", str(ad), "--frames", "3"])  # main.cpp:33-35: missing frame
