@@ -75,6 +75,11 @@ void launch_conv_direct(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile
 // the network's first layer (conv_stem.hip): 3x3 / stride 2, 8 stored -> 48 channels, an HBM stream
 bool conv_stem_supported(const ConvArgs& a);
 void launch_conv_stem(DeviceCtx& ctx, hipStream_t stream, ConvArgs a);
+// the network's second layer (conv_ws_s2.hip): 3x3 / stride 2, 48 -> 96 channels on a 320-wide map,
+// weights stationary in registers, input rows de-interleaved by column parity in an LDS ring
+int conv_ws_s2_num_variants();
+bool conv_ws_s2_supported(const ConvArgs& a, int variant);  // variant < 0: any
+void launch_conv_ws_s2(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant);
 // picks the kernel family and tile for a layer (RMR_CONV=igemm|dma overrides) and launches it
 void launch_conv_auto(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a);
 

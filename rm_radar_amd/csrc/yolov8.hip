@@ -330,7 +330,9 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
 // (layer, batch) -- the analogue of the reference's TensorRT engine build (detector.cpp:177-243).
 void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     const int split = choice / 1000, c = choice % 1000;
-    if (c == 500) {
+    if (c >= 600) {
+        launch_conv_ws_s2(ctx_, s, a, c - 600);
+    } else if (c == 500) {
         launch_conv_stem(ctx_, s, a);
     } else if (c >= 400) {
         launch_conv_direct(ctx_, s, a, c - 400);
@@ -365,6 +367,9 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
         for (int t = 0; t < conv_direct_num_tiles(); ++t)
             if (conv_direct_supported(a, t)) cands.push_back(400 + t);
     if (conv_stem_supported(a)) cands.push_back(500);
+    if (conv_ws_s2_supported(a, -1))
+        for (int v = 0; v < conv_ws_s2_num_variants(); ++v)
+            if (conv_ws_s2_supported(a, v)) cands.push_back(600 + v);
     if (conv_ws_supported(a, -1))
         for (int v = 0; v < conv_ws_num_variants(); ++v)
             if (conv_ws_supported(a, v)) cands.push_back(300 + v);
@@ -427,13 +432,14 @@ void Yolov8::load_tuning() {
     std::string tag;
     int version = 0, n_ops = 0, w = 0, h = 0;
     f >> tag >> version >> n_ops >> w >> h;
-    if (tag != "rmr-tune" || version != 6 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_) return;
+    if (tag != "rmr-tune" || version != 7 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_) return;
     int op, n, choice;
     while (f >> op >> n >> choice) {
         if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV) continue;
         const int c = choice % 1000, split = choice / 1000;
         const bool ok = choice >= 0 && split <= 64 && (split == 0 || (c >= 100 && c < 200)) &&
-                        (c == 500 ? true
+                        (c >= 600 ? c - 600 < conv_ws_s2_num_variants()
+                         : c == 500 ? true
                          : c >= 400 ? c - 400 < conv_direct_num_tiles()
                          : c >= 300 ? c - 300 < conv_ws_num_variants()
                          : c >= 200 ? c - 200 < conv_halo_num_tiles()
@@ -445,7 +451,7 @@ void Yolov8::load_tuning() {
 void Yolov8::save_tuning() {
     std::ofstream f(tune_path_, std::ios::trunc);
     if (!f) return;  // read-only location: tune again next time
-    f << "rmr-tune 6 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << "\n";
+    f << "rmr-tune 7 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << "\n";
     for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
 }
 

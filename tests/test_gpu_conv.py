@@ -201,6 +201,21 @@ def test_conv_stem(rmr):
                    False, tile=500)  # stride 1
 
 
+def test_conv_ws_stride2(rmr):
+    # conv_ws_s2.hip (ids 600..): 3x3 / stride 2, 48 -> 96 channels, 320-wide input; ring rows are
+    # de-interleaved by column parity, each workgroup takes one half of the map's width
+    for v, rows in enumerate([40, 20, 10, 8, 4, 2]):
+        run_case(rmr, 2, 80, 320, 48, 96, 3, 2, True, False, tile=600 + v, seed=160 + v)   # Ho = 40
+    run_case(rmr, 1, 320, 320, 48, 96, 3, 2, True, False, tile=600, seed=170)              # the real layer, 4 strips x 2 halves
+    run_case(rmr, 3, 12, 320, 48, 89, 3, 2, False, False, tile=605, seed=171)              # 89 channels padded to 96, no activation
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 16, 160, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 2, 1,
+                   False, tile=600)  # input width 160
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 16, 320, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
+                   False, tile=600)  # stride 1
+
+
 def test_conv_matches_c_oracle(rmr, oracle):
     # the plain-C direct convolution (oracle/rmr_oracle.c) agrees with both
     rng = np.random.default_rng(5)
