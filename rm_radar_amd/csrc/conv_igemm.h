@@ -75,6 +75,11 @@ void launch_conv_direct(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile
 // the network's first layer (conv_stem.hip): 3x3 / stride 2, 8 stored -> 48 channels, an HBM stream
 bool conv_stem_supported(const ConvArgs& a);
 void launch_conv_stem(DeviceCtx& ctx, hipStream_t stream, ConvArgs a);
+// the same layer sampling the BGR u8 source frames itself (letterbox fused in): descs is a DEVICE array
+// of a.N descriptors, a.in is not read
+struct LetterboxDesc;
+void launch_conv_stem_letterbox(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, const LetterboxDesc* descs, int fill,
+                                float scale);
 // the network's second layer (conv_ws_s2.hip): 3x3 / stride 2, 48 -> 96 channels on a 320-wide map,
 // weights stationary in registers, input rows de-interleaved by column parity in an LDS ring
 int conv_ws_s2_num_variants();

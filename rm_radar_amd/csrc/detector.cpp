@@ -106,9 +106,8 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
     }
     RMR_HIP(hipMemcpyAsync(descs_dev_.p, descs_pin_.p, n * sizeof(LetterboxDesc), hipMemcpyHostToDevice, stream_));
     RMR_HIP(hipMemcpyAsync(pp_dev_.p, pp_pin_.p, n * sizeof(rmr_preparam), hipMemcpyHostToDevice, stream_));
-    launch_letterbox(ctx_, stream_, descs_dev_.p, n, cfg_.input_width, cfg_.input_height, 128, 1 / 255.f,
-                     LB_F16_NHWC8, net_->input());
-    net_->forward(stream_, n);
+    // letterbox (fill 128, 1/255) + network; the first layer samples the frames itself where it can
+    net_->forward(stream_, n, descs_dev_.p, 128, 1 / 255.f);
     if (!post) return;
     launch_postprocess(ctx_, stream_, net_->output(), n, net_->channels(), net_->anchors(), net_->nc(),
                        cfg_.nms_thresh, cfg_.conf_thresh, pp_dev_.p, post_scratch_.p, dets_dev_.p,

@@ -22,33 +22,8 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const LetterboxDesc* __r
     if (x >= out_w || y >= out_h) return;
     const LetterboxDesc d = descs[img];
 
-    unsigned char px[3] = {(unsigned char)fill, (unsigned char)fill, (unsigned char)fill};
-    const int rx = x - d.left;
-    const int ry = y - d.top;
-    if (rx >= 0 && rx < d.rw && ry >= 0 && ry < d.rh) {
-        // detector.cu:53-79
-        const float src_y = (float)ry * (float)d.crop_h / (float)d.rh;
-        const float src_x = (float)rx * (float)d.crop_w / (float)d.rw;
-        const int y_lo = (int)src_y;
-        const int y_hi = min(y_lo + 1, d.crop_h - 1);
-        const int x_lo = (int)src_x;
-        const int x_hi = min(x_lo + 1, d.crop_w - 1);
-        const float ly = src_y - (float)y_lo;
-        const float lx = src_x - (float)x_lo;
-        const float hy = 1.f - ly;
-        const float hx = 1.f - lx;
-        const uint8_t* r0 = d.src + (size_t)(d.crop_y + y_lo) * d.src_stride + (size_t)d.crop_x * 3;
-        const uint8_t* r1 = d.src + (size_t)(d.crop_y + y_hi) * d.src_stride + (size_t)d.crop_x * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float tl = (float)r0[x_lo * 3 + c] * hy * hx;
-            const float tr = (float)r0[x_hi * 3 + c] * hy * lx;
-            const float bl = (float)r1[x_lo * 3 + c] * ly * hx;
-            const float br = (float)r1[x_hi * 3 + c] * ly * lx;
-            const float value = tl + tr + bl + br;
-            px[c] = (unsigned char)value;
-        }
-    }
+    unsigned char px[3];
+    letterbox_pixel(d, x, y, fill, px);
 
     const size_t plane = (size_t)out_w * out_h;
     const size_t pix = (size_t)y * out_w + x;
@@ -65,16 +40,7 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const LetterboxDesc* __r
         o[2 * plane] = (float)px[0] * scale;
     } else {
         // network input: f16 NHWC padded to 8 channels (16 B per pixel, one store)
-        union {
-            __half h[8];
-            uint4 v;
-        } u;
-        u.h[0] = __float2half_rn((float)px[2] * scale);
-        u.h[1] = __float2half_rn((float)px[1] * scale);
-        u.h[2] = __float2half_rn((float)px[0] * scale);
-#pragma unroll
-        for (int c = 3; c < 8; ++c) u.h[c] = __float2half_rn(0.f);
-        ((uint4*)out)[(size_t)img * plane + pix] = u.v;
+        ((uint4*)out)[(size_t)img * plane + pix] = letterbox_pixel_f16x8(px, scale);
     }
 }
 

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.h"
+#include "preprocess.h"
 #include "conv_igemm.h"
 
 namespace rmr {
@@ -50,6 +51,10 @@ class Yolov8 {
     // network output: f32 [batch][4+nc][anchors], the tensor TensorRT hands to postprocess
     float* output() { return output_.p; }
     void forward(hipStream_t s, int batch);
+    // The same, taking the frames / crops themselves: src is a DEVICE array of batch letterbox
+    // descriptors (preprocess.h).  Where the first layer has the stem shape it samples the sources
+    // itself (conv_stem.hip) and input() is not written; otherwise the canvases are built first.
+    void forward(hipStream_t s, int batch, const LetterboxDesc* src, int fill, float scale);
     ~Yolov8();
 
    private:
@@ -80,6 +85,7 @@ class Yolov8 {
     View c2f(const WeightPack& p, const std::string& name, const View& x, int n, bool shortcut,
              const View* out_view);
     void run_op(hipStream_t s, int op_index, int chunk_n, size_t img_base);
+    ConvArgs conv_args(int op_index, int chunk_n, size_t img_base);
     int tune_conv(hipStream_t s, const ConvArgs& a);
 
     DeviceCtx& ctx_;
@@ -107,10 +113,16 @@ class Yolov8 {
     struct Graph {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
+        const LetterboxDesc* src = nullptr;  // captured by address
     };
     std::map<int, Graph> graphs_;
     int graph_max_batch_ = 8;
     bool all_tuned(int n) const;
+    // letterbox fused into the first layer (RMR_FUSE_LB=0 keeps the separate kernel)
+    bool fuse_lb_ = true;
+    const LetterboxDesc* lb_src_ = nullptr;  // set for the duration of a fused forward()
+    int lb_fill_ = 0;
+    float lb_scale_ = 0.f;
     std::string tune_path_;  // '<pack>.tune': choices persist like the reference's engine cache
     void load_tuning();
     void save_tuning();

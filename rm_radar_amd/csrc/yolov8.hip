@@ -208,6 +208,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     if (const char* e = std::getenv("RMR_CHUNK")) chunk = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RMR_AUTOTUNE")) autotune_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("RMR_GRAPH")) graph_max_batch_ = atoi(e);
+    if (const char* e = std::getenv("RMR_FUSE_LB")) fuse_lb_ = atoi(e) != 0;
     chunk_ = std::min(chunk, max_batch);
 
     int ch[5];
@@ -353,6 +354,9 @@ void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
 }
 
 int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
+    // the first layer has its own kernel (2x the next best at every batch size), which is also the
+    // one that samples the frames directly: the same arithmetic whichever way the input arrives
+    if (conv_stem_supported(a)) return 500;
     std::vector<int> cands;
     for (int t = 0; t < conv_num_tiles(); ++t)
         if (a.Cout_pad % conv_tile(t).bn == 0) cands.push_back(t);
@@ -366,7 +370,6 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (conv_direct_supported(a, -1) && a.M <= 64 * ctx_.num_cus)
         for (int t = 0; t < conv_direct_num_tiles(); ++t)
             if (conv_direct_supported(a, t)) cands.push_back(400 + t);
-    if (conv_stem_supported(a)) cands.push_back(500);
     if (conv_ws_s2_supported(a, -1))
         for (int v = 0; v < conv_ws_s2_num_variants(); ++v)
             if (conv_ws_s2_supported(a, v)) cands.push_back(600 + v);
@@ -455,47 +458,59 @@ void Yolov8::save_tuning() {
     for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
 }
 
+ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
+    const Op& op = ops_[op_index];
+    auto hptr = [&](const View& v) { return arena_.p + v.off * chunk_; };
+    auto fptr = [&](const View& v) { return arena32_.p + v.off * chunk_; };
+    const ConvW& cw = convs_[op.conv];
+    ConvArgs a{};
+    a.in = op.in_is_input ? input_.p + img0 * in_h_ * in_w_ * 8 : hptr(op.in);
+    a.in_cs = op.in.cs;
+    a.in_co = op.in.co;
+    a.N = n;
+    a.H = op.in.h;
+    a.W = op.in.w;
+    a.Cin = cw.cin;
+    a.Ho = op.out.h;
+    a.Wo = op.out.w;
+    a.KH = a.KW = cw.k;
+    a.stride = op.stride;
+    a.pad = cw.k / 2;
+    a.wt = cw.w.p;
+    a.bias = cw.b.p;
+    if (op.out_f32)
+        a.out32 = fptr(op.out);
+    else
+        a.out = hptr(op.out);
+    a.out_cs = op.out.cs;
+    a.out_co = op.out.co;
+    if (op.res.c) {
+        a.res = hptr(op.res);
+        a.res_cs = op.res.cs;
+        a.res_co = op.res.co;
+    }
+    a.Cout_pad = cw.cout_pad;
+    a.K = cw.K;
+    a.Kp = cw.Kp;
+    a.M = n * a.Ho * a.Wo;
+    a.act = op.act;
+    a.in_bytes = (unsigned)((size_t)n * a.H * a.W * a.in_cs * sizeof(__half));
+    a.wt_bytes = (unsigned)((size_t)cw.cout_pad * cw.Kp * sizeof(__half));
+    a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
+    return a;
+}
+
 void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
     const Op& op = ops_[op_index];
     auto hptr = [&](const View& v) { return arena_.p + v.off * chunk_; };
     auto fptr = [&](const View& v) { return arena32_.p + v.off * chunk_; };
     switch (op.kind) {
         case OP_CONV: {
-            const ConvW& cw = convs_[op.conv];
-            ConvArgs a{};
-            a.in = op.in_is_input ? input_.p + img0 * in_h_ * in_w_ * 8 : hptr(op.in);
-            a.in_cs = op.in.cs;
-            a.in_co = op.in.co;
-            a.N = n;
-            a.H = op.in.h;
-            a.W = op.in.w;
-            a.Cin = cw.cin;
-            a.Ho = op.out.h;
-            a.Wo = op.out.w;
-            a.KH = a.KW = cw.k;
-            a.stride = op.stride;
-            a.pad = cw.k / 2;
-            a.wt = cw.w.p;
-            a.bias = cw.b.p;
-            if (op.out_f32)
-                a.out32 = fptr(op.out);
-            else
-                a.out = hptr(op.out);
-            a.out_cs = op.out.cs;
-            a.out_co = op.out.co;
-            if (op.res.c) {
-                a.res = hptr(op.res);
-                a.res_cs = op.res.cs;
-                a.res_co = op.res.co;
+            const ConvArgs a = conv_args(op_index, n, img0);
+            if (op.in_is_input && lb_src_) {
+                launch_conv_stem_letterbox(ctx_, s, a, lb_src_ + img0, lb_fill_, lb_scale_);
+                break;
             }
-            a.Cout_pad = cw.cout_pad;
-            a.K = cw.K;
-            a.Kp = cw.Kp;
-            a.M = n * a.Ho * a.Wo;
-            a.act = op.act;
-            a.in_bytes = (unsigned)((size_t)n * a.H * a.W * a.in_cs * sizeof(__half));
-            a.wt_bytes = (unsigned)((size_t)cw.cout_pad * cw.Kp * sizeof(__half));
-            a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
             if (!autotune_) {
                 launch_conv_auto(ctx_, s, a);
                 break;
@@ -533,8 +548,31 @@ Yolov8::~Yolov8() {
 
 bool Yolov8::all_tuned(int n) const {
     for (int i = 0; i < (int)ops_.size(); ++i)
-        if (ops_[i].kind == OP_CONV && autotune_ && !tuned_.count({i, n})) return false;
+        if (ops_[i].kind == OP_CONV && autotune_ && !(ops_[i].in_is_input && lb_src_) && !tuned_.count({i, n})) return false;
     return true;
+}
+
+void Yolov8::forward(hipStream_t s, int batch, const LetterboxDesc* src, int fill, float scale) {
+    if (!src) fail(RMR_ERR_INVALID_ARGUMENT, "forward: no letterbox descriptors");
+    if (batch <= 0) return;
+    bool fused = fuse_lb_ && !ops_.empty() && ops_[0].kind == OP_CONV && ops_[0].in_is_input;
+    if (fused) {
+        const ConvArgs a = conv_args(0, 1, 0);
+        fused = conv_stem_supported(a) && !a.out32;
+    }
+    if (!fused) {
+        launch_letterbox(ctx_, s, src, batch, in_w_, in_h_, fill, scale, LB_F16_NHWC8, input_.p);
+        forward(s, batch);
+        return;
+    }
+    struct Reset {
+        const LetterboxDesc*& p;
+        ~Reset() { p = nullptr; }
+    } reset{lb_src_};
+    lb_src_ = src;
+    lb_fill_ = fill;
+    lb_scale_ = scale;
+    forward(s, batch);
 }
 
 void Yolov8::forward(hipStream_t s, int batch) {
@@ -542,8 +580,15 @@ void Yolov8::forward(hipStream_t s, int batch) {
     // graph replay: one chunk, every layer tuned (tuning synchronises), no per-kernel events
     if (batch > 0 && batch <= graph_max_batch_ && batch <= chunk_ && !ctx_.prof.on && all_tuned(batch)) {
         auto it = graphs_.find(batch);
+        if (it != graphs_.end() && it->second.src != lb_src_) {  // captured with another source array
+            (void)hipGraphExecDestroy(it->second.exec);
+            (void)hipGraphDestroy(it->second.graph);
+            graphs_.erase(it);
+            it = graphs_.end();
+        }
         if (it == graphs_.end()) {
             Graph g;
+            g.src = lb_src_;
             RMR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             try {
                 for (int i = 0; i < (int)ops_.size(); ++i) run_op(s, i, batch, 0);

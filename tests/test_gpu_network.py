@@ -236,3 +236,27 @@ def test_robot_detector_matches_oracle(rmr, oracle, packs, refs, images):
     gf = rd.detect_batch([img], forced_crops=fc)
     assert sorted(r.rect for r in gf[0]) == sorted((float(a), float(b), float(c), float(d)) for a, b, c, d in fc[0]) or len(gf[0]) <= 2
     rd.close()
+
+
+@pytest.mark.parametrize("n", [3, 64])
+def test_first_layer_sampling_the_frames_equals_letterbox_then_network(rmr, packs, images, monkeypatch, n):
+    """Detector::enqueue hands the frames / crops to the network, whose first layer resizes, pads
+    and scales them itself (conv_stem.hip, LB instantiation).  With RMR_FUSE_LB=0 the stand-alone
+    letterbox kernel (bit-exact against oracle.preprocess in test_gpu_prepost.py) builds the
+    canvases first and the same layer kernel reads them: the head tensors must be bit-identical --
+    full frames (shrunk), magnified crops, a crop touching the frame edge, a 1:1 crop."""
+    crops = [None, (100, 100, 300, 200), (0, 0, 640, 640), (810 - 111, 50, 111, 333), None, (5, 7, 64, 48)]
+    srcs = [images[0], images[0], images[0], images[1], images[2], images[2]]
+    batch = [srcs[i % len(srcs)] for i in range(n)]
+    cr = [crops[i % len(crops)] or (0, 0, batch[i].shape[1], batch[i].shape[0]) for i in range(n)]
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("RMR_FUSE_LB", fuse)
+        det = rmr.Detector(packs[1], 12, (2592, 2048), n, conf_thresh=0.5)
+        got, pps = det.infer(batch, crops=cr)
+        again, _ = det.infer(batch, crops=cr)  # batch <= 8: the second call replays the captured graph
+        assert np.array_equal(got, again)
+        out.append(got)
+        det.close()
+    assert np.isfinite(out[0]).all()
+    assert np.array_equal(out[0], out[1])
