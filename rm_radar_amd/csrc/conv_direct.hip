@@ -250,7 +250,7 @@ int conv_direct_num_tiles() { return kNumDirectTiles; }
 ConvTile conv_direct_tile(int id) { return ConvTile{kDirectTiles[id].bm, kDirectTiles[id].bn, 32}; }
 
 bool conv_direct_supported(const ConvArgs& a, int tile) {
-    if (a.Cin % 32 || a.KH * a.KW > 16 || a.in_bytes == 0 || a.wt_bytes == 0) return false;
+    if (a.Cin % 32 || a.KH * a.KW > 16 || a.in_bytes == 0 || a.wt_bytes == 0 || a.pre) return false;
     if (tile < 0) return true;
     if (tile >= kNumDirectTiles) return false;
     const DirectTile& t = kDirectTiles[tile];

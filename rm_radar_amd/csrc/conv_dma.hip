@@ -340,11 +340,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
     for (int i = 0; i < MREP; ++i) {
         const int m = m0 + (wm * MREP + i) * 16 + px;
         if (m >= a.M) continue;
+        long mpre = 0;  // the half-resolution pixel under output pixel m
+        if (a.pre) {
+            const int hw = a.Ho * a.Wo, img = m / hw, rem = m - img * hw, y = rem / a.Wo, x = rem - y * a.Wo;
+            mpre = ((long)img * (a.Ho >> 1) + (y >> 1)) * (a.Wo >> 1) + (x >> 1);
+        }
 #pragma unroll
         for (int j = 0; j < NREP; ++j) {
             const int n = n0 + (wn * NREP + j) * 16 + cq;
             const float4 b = *(const float4*)(a.bias + n);
             float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
+            if (a.pre) {
+                const float4 t = *(const float4*)(a.pre + mpre * a.pre_cs + n);
+                v[0] += t.x, v[1] += t.y, v[2] += t.z, v[3] += t.w;
+            }
             if (a.act) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);

@@ -21,6 +21,12 @@ struct ConvArgs {
     int out_cs, out_co;
     const __half* res;  // optional residual view, added after the activation
     int res_cs, res_co;
+    // optional f32 addend at HALF the output resolution, added before the activation: pixel (y, x)
+    // takes pre[(y/2, x/2)].  A 1x1 convolution commutes with nearest-neighbour upsampling, so
+    // conv1x1(concat[up2x(A), B]) = act(W_B.B + bias + up2x(W_A.A)): `pre` is W_A.A (conv_igemm and
+    // conv_dma only; Ho and Wo even)
+    const float* pre;
+    int pre_cs;
     int Cout_pad;       // multiple of the tile's BN
     int K, Kp, M;       // K = KH*KW*Cin, Kp = K rounded up to 64, M = N*Ho*Wo
     int act;            // 1 = SiLU

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, const 
 bool conv_stem_supported(const ConvArgs& a) {
     return a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.Cin == 8 && a.Cout_pad == 48 && a.Kp >= 96 &&
            a.Wo % ST_TW == 0 && a.Ho % ST_TH == 0 && a.Ho == a.H / 2 && a.Wo == a.W / 2 && a.H % 2 == 0 && a.W % 2 == 0 &&
-           !a.res;
+           !a.res && !a.pre;
 }
 
 static void launch_stem(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, const LetterboxDesc* descs, int fill,

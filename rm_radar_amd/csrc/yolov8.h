@@ -68,6 +68,7 @@ class Yolov8 {
         OpKind kind;
         int conv = -1;      // index into convs_
         View in, out, res;  // res.c == 0 : none
+        View pre;           // pre.c != 0: f32 half-resolution addend before the activation (ConvArgs::pre)
         bool in_is_input = false;
         bool out_f32 = false;
         int stride = 1, act = 1;
@@ -78,12 +79,17 @@ class Yolov8 {
 
     View alloc(int h, int w, int c, bool f32 = false);
     static View slice(const View& v, int co, int c);
-    int add_conv_weights(const WeightPack& p, const std::string& name, int cin_pad);
+    // ci0 / ci_n: the slice of input channels to keep (ci_n = 0: all); no_bias: a zero bias
+    int add_conv_weights(const WeightPack& p, const std::string& name, int cin_pad, int ci0 = 0, int ci_n = 0,
+                         bool no_bias = false);
     int add_fused_head_weights(const WeightPack& p, const std::string& a, const std::string& b);
     void conv(int widx, const View& in, const View& out, int stride, int act, const View* res = nullptr,
-              bool out_f32 = false, bool in_is_input = false);
+              bool out_f32 = false, bool in_is_input = false, const View* pre = nullptr);
+    // up: x is concat[up2x(*up), skip] with the skip in x's trailing channels -- cv1 is then computed
+    // as W_skip.skip + up2x(W_up.up) and the upsampled slice of x is never written or read
     View c2f(const WeightPack& p, const std::string& name, const View& x, int n, bool shortcut,
-             const View* out_view);
+             const View* out_view, const View* up = nullptr);
+    bool fuse_up_ = true;  // RMR_FUSE_UP=0: upsample kernel + cv1 over the concat
     void run_op(hipStream_t s, int op_index, int chunk_n, size_t img_base);
     ConvArgs conv_args(int op_index, int chunk_n, size_t img_base);
     int tune_conv(hipStream_t s, const ConvArgs& a);
@@ -124,6 +130,7 @@ class Yolov8 {
     int lb_fill_ = 0;
     float lb_scale_ = 0.f;
     std::string tune_path_;  // '<pack>.tune': choices persist like the reference's engine cache
+    unsigned long long plan_signature() const;
     void load_tuning();
     void save_tuning();
 };

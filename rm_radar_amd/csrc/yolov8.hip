@@ -94,22 +94,35 @@ View Yolov8::slice(const View& v, int co, int c) {
     return s;
 }
 
-int Yolov8::add_conv_weights(const WeightPack& p, const std::string& name, int cin_pad) {
+int Yolov8::add_conv_weights(const WeightPack& p, const std::string& name, int cin_pad, int ci0, int ci_n, bool no_bias) {
     const auto& w = p.get(name + ".weight");
     const auto& b = p.get(name + ".bias");
     if (w.dims.size() != 4 || w.dims[2] != w.dims[3]) fail(RMR_ERR_RUNTIME, "tensor '%s.weight' is not OIkk", name.c_str());
+    const int cin_all = (int)w.dims[1];
+    if (ci_n == 0) ci0 = 0, ci_n = cin_all;
+    if (ci0 < 0 || ci0 + ci_n > cin_all) fail(RMR_ERR_LOGIC, "conv '%s': channel slice outside the tensor", name.c_str());
     ConvW cw;
     cw.cout = (int)w.dims[0];
-    cw.cin = cin_pad > 0 ? cin_pad : (int)w.dims[1];
+    cw.cin = cin_pad > 0 ? cin_pad : ci_n;
     cw.k = (int)w.dims[2];
     cw.cout_pad = (cw.cout + 15) / 16 * 16;
-    if ((int)w.dims[1] > cw.cin || cw.cin % 8)
-        fail(RMR_ERR_RUNTIME, "conv '%s': %u input channels cannot be consumed in 8-channel chunks", name.c_str(), w.dims[1]);
+    if (ci_n > cw.cin || cw.cin % 8)
+        fail(RMR_ERR_RUNTIME, "conv '%s': %d input channels cannot be consumed in 8-channel chunks", name.c_str(), ci_n);
     if (b.data.size() != (size_t)cw.cout) fail(RMR_ERR_RUNTIME, "tensor '%s.bias' has the wrong size", name.c_str());
+    const size_t kk = (size_t)cw.k * cw.k;
+    std::vector<float> sub;  // [cout][ci_n][k][k]
+    const float* wsrc = w.data.data();
+    if (ci_n != cin_all) {
+        sub.resize((size_t)cw.cout * ci_n * kk);
+        for (int o = 0; o < cw.cout; ++o)
+            std::copy(wsrc + ((size_t)o * cin_all + ci0) * kk, wsrc + ((size_t)o * cin_all + ci0 + ci_n) * kk,
+                      sub.begin() + (size_t)o * ci_n * kk);
+        wsrc = sub.data();
+    }
     std::vector<__half> packed;
-    pack_conv_weights(w.data.data(), cw.cout, (int)w.dims[1], cw.k, cw.k, cw.cin, cw.cout_pad, packed, cw.K, cw.Kp);
+    pack_conv_weights(wsrc, cw.cout, ci_n, cw.k, cw.k, cw.cin, cw.cout_pad, packed, cw.K, cw.Kp);
     std::vector<float> bias(cw.cout_pad, 0.f);
-    std::copy(b.data.begin(), b.data.end(), bias.begin());
+    if (!no_bias) std::copy(b.data.begin(), b.data.end(), bias.begin());
     cw.w.alloc(packed.size());
     cw.b.alloc(bias.size());
     RMR_HIP(hipMemcpy(cw.w.p, packed.data(), packed.size() * sizeof(__half), hipMemcpyHostToDevice));
@@ -148,7 +161,7 @@ int Yolov8::add_fused_head_weights(const WeightPack& p, const std::string& a, co
 }
 
 void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act, const View* res,
-                  bool out_f32, bool in_is_input) {
+                  bool out_f32, bool in_is_input, const View* pre) {
     const ConvW& cw = convs_[widx];
     if (in.c != cw.cin) fail(RMR_ERR_LOGIC, "planner: conv %d expects %d input channels, view has %d", widx, cw.cin, in.c);
     if (out.c != cw.cout_pad && !(out_f32 && out.cs == cw.cout_pad))
@@ -159,6 +172,11 @@ void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act
     op.in = in;
     op.out = out;
     if (res) op.res = *res;
+    if (pre) {
+        if (pre->h * 2 != out.h || pre->w * 2 != out.w || pre->cs != cw.cout_pad || pre->co != 0 || cw.k != 1)
+            fail(RMR_ERR_LOGIC, "planner: conv %d: the half-resolution addend does not fit", widx);
+        op.pre = *pre;
+    }
     op.stride = stride;
     op.act = act;
     op.out_f32 = out_f32;
@@ -171,12 +189,24 @@ void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act
 // C2f (Ultralytics nn/modules/block.py): cv1 -> split -> n bottlenecks chained on the last
 // half -> cv2 over the (2+n)*c concat.  The concat buffer IS where everything is written.
 View Yolov8::c2f(const WeightPack& p, const std::string& name, const View& x, int n, bool shortcut,
-                 const View* out_view) {
+                 const View* out_view, const View* up) {
     const int cout = (int)p.get(name + ".cv2.conv.weight").dims[0];
     const int c = cout / 2;
     if (c % 16) fail(RMR_ERR_RUNTIME, "C2f '%s': hidden width %d is not a multiple of 16", name.c_str(), c);
     View cat = alloc(x.h, x.w, (2 + n) * c);
-    conv(add_conv_weights(p, name + ".cv1.conv", 0), x, slice(cat, 0, 2 * c), 1, 1);
+    if (up) {
+        // cv1 over concat[up2x(U), S] = SiLU(W_S.S + b + up2x(W_U.U)): the U half at a quarter of the
+        // pixels, in f32, added by the S half's epilogue (ConvArgs::pre)
+        const int cu = up->c, cs = x.c;
+        View t = alloc(up->h, up->w, 2 * c, true);
+        conv(add_conv_weights(p, name + ".cv1.conv", 0, 0, cu, true), *up, t, 1, 0, nullptr, true);
+        conv(add_conv_weights(p, name + ".cv1.conv", 0, cu, cs), x, slice(cat, 0, 2 * c), 1, 1, nullptr, false, false, &t);
+        // the model's own count for this layer: 2 * K * N at full resolution (the two launches
+        // above declared what they execute, 3/4 of the U half less)
+        flops_ += 2.0 * x.h * x.w * (double)(2 * c) * cu * 0.75;
+    } else {
+        conv(add_conv_weights(p, name + ".cv1.conv", 0), x, slice(cat, 0, 2 * c), 1, 1);
+    }
     for (int i = 0; i < n; ++i) {
         View tmp = alloc(x.h, x.w, c);
         const View prev = slice(cat, (1 + i) * c, c);
@@ -209,6 +239,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     if (const char* e = std::getenv("RMR_AUTOTUNE")) autotune_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("RMR_GRAPH")) graph_max_batch_ = atoi(e);
     if (const char* e = std::getenv("RMR_FUSE_LB")) fuse_lb_ = atoi(e) != 0;
+    if (const char* e = std::getenv("RMR_FUSE_UP")) fuse_up_ = atoi(e) != 0;
     chunk_ = std::min(chunk, max_batch);
 
     int ch[5];
@@ -230,13 +261,16 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     View l2 = c2f(p, "model.2", l1, n0, true, nullptr);
     View l3 = alloc(H / 8, W / 8, ch[2]);
     conv(add_conv_weights(p, "model.3.conv", 0), l2, l3, 2, 1);
-    View cat14 = alloc(H / 8, W / 8, ch[3] + ch[2]);  // [up(model.12), model.4]
-    View l4v = slice(cat14, ch[3], ch[2]);
+    // the two nearest-neighbour upsamples feed 1x1 convolutions only: folded into them (c2f) where the
+    // channel counts suit the kernels that carry the addend; the concat buffers then hold the skip alone
+    const bool fold11 = fuse_up_ && ch[4] % 32 == 0 && ch[3] % 32 == 0, fold14 = fuse_up_ && ch[3] % 32 == 0 && ch[2] % 32 == 0;
+    View cat14 = alloc(H / 8, W / 8, fold14 ? ch[2] : ch[3] + ch[2]);  // [up(model.12), model.4]
+    View l4v = fold14 ? cat14 : slice(cat14, ch[3], ch[2]);
     View l4 = c2f(p, "model.4", l3, n1, true, &l4v);
     View l5 = alloc(H / 16, W / 16, ch[3]);
     conv(add_conv_weights(p, "model.5.conv", 0), l4, l5, 2, 1);
-    View cat11 = alloc(H / 16, W / 16, ch[4] + ch[3]);  // [up(model.9), model.6]
-    View l6v = slice(cat11, ch[4], ch[3]);
+    View cat11 = alloc(H / 16, W / 16, fold11 ? ch[3] : ch[4] + ch[3]);  // [up(model.9), model.6]
+    View l6v = fold11 ? cat11 : slice(cat11, ch[4], ch[3]);
     View l6 = c2f(p, "model.6", l5, n2, true, &l6v);
     View l7 = alloc(H / 32, W / 32, ch[4]);
     conv(add_conv_weights(p, "model.7.conv", 0), l6, l7, 2, 1);
@@ -256,24 +290,19 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     View l9 = slice(cat20, ch[3], ch[4]);
     conv(add_conv_weights(p, "model.9.cv2.conv", 0), spp, l9, 1, 1);
     // neck
-    {
+    const auto upsample = [&](const View& in, const View& out) {
         Op op{};
         op.kind = OP_UP;
-        op.in = l9;
-        op.out = slice(cat11, 0, ch[4]);
+        op.in = in;
+        op.out = out;
         ops_.push_back(op);
-    }
+    };
+    if (!fold11) upsample(l9, slice(cat11, 0, ch[4]));
     View cat17 = alloc(H / 16, W / 16, ch[2] + ch[3]);  // [model.16, model.12]
     View l12v = slice(cat17, ch[2], ch[3]);
-    View l12 = c2f(p, "model.12", cat11, nh, false, &l12v);
-    {
-        Op op{};
-        op.kind = OP_UP;
-        op.in = l12;
-        op.out = slice(cat14, 0, ch[3]);
-        ops_.push_back(op);
-    }
-    View l15 = c2f(p, "model.15", cat14, nh, false, nullptr);
+    View l12 = c2f(p, "model.12", cat11, nh, false, &l12v, fold11 ? &l9 : nullptr);
+    if (!fold14) upsample(l12, slice(cat14, 0, ch[3]));
+    View l15 = c2f(p, "model.15", cat14, nh, false, nullptr, fold14 ? &l12 : nullptr);
     conv(add_conv_weights(p, "model.16.conv", 0), l15, slice(cat17, 0, ch[2]), 2, 1);
     View l18 = c2f(p, "model.18", cat17, nh, false, nullptr);
     conv(add_conv_weights(p, "model.19.conv", 0), l18, slice(cat20, 0, ch[3]), 2, 1);
@@ -363,17 +392,17 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (conv_dma_supported(a))
         for (int t = 0; t < conv_dma_num_tiles(); ++t)
             if (a.Cout_pad % conv_dma_tile(t).bn == 0) cands.push_back(100 + t);
-    if (conv_halo_supported(a, -1))
+    if (!a.pre && conv_halo_supported(a, -1))
         for (int t = 0; t < conv_halo_num_tiles(); ++t)
             if (conv_halo_supported(a, t)) cands.push_back(200 + t);
     // fragment-direct tiles only where the staged kernels cannot fill the chip
     if (conv_direct_supported(a, -1) && a.M <= 64 * ctx_.num_cus)
         for (int t = 0; t < conv_direct_num_tiles(); ++t)
             if (conv_direct_supported(a, t)) cands.push_back(400 + t);
-    if (conv_ws_s2_supported(a, -1))
+    if (!a.pre && conv_ws_s2_supported(a, -1))
         for (int v = 0; v < conv_ws_s2_num_variants(); ++v)
             if (conv_ws_s2_supported(a, v)) cands.push_back(600 + v);
-    if (conv_ws_supported(a, -1))
+    if (!a.pre && conv_ws_supported(a, -1))
         for (int v = 0; v < conv_ws_num_variants(); ++v)
             if (conv_ws_supported(a, v)) cands.push_back(300 + v);
     // split-K variants where the plain grid cannot fill the chip (small batches)
@@ -429,13 +458,27 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
 
 // The tuning result is cached next to the weight pack, as the reference caches its TensorRT
 // engine next to the ONNX file (detector.cpp:74-99).  One line per entry: "op n choice" after a header with the op count and input size.
+// The op list depends on the pack and on the planner's options (RMR_FUSE_UP): entries are per op index,
+// so a cache written for another plan must not be read.
+unsigned long long Yolov8::plan_signature() const {
+    unsigned long long h = 1469598103934665603ull;
+    const auto mix = [&](long long v) { h = (h ^ (unsigned long long)v) * 1099511628211ull; };
+    for (const Op& op : ops_) {
+        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c);
+        if (op.kind == OP_CONV) mix(convs_[op.conv].K), mix(convs_[op.conv].cout_pad);
+    }
+    return h;
+}
+
 void Yolov8::load_tuning() {
     std::ifstream f(tune_path_);
     if (!f) return;
     std::string tag;
     int version = 0, n_ops = 0, w = 0, h = 0;
-    f >> tag >> version >> n_ops >> w >> h;
-    if (tag != "rmr-tune" || version != 7 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_) return;
+    unsigned long long sig = 0;
+    f >> tag >> version >> n_ops >> w >> h >> sig;
+    if (tag != "rmr-tune" || version != 8 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_ || sig != plan_signature())
+        return;
     int op, n, choice;
     while (f >> op >> n >> choice) {
         if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV) continue;
@@ -454,7 +497,7 @@ void Yolov8::load_tuning() {
 void Yolov8::save_tuning() {
     std::ofstream f(tune_path_, std::ios::trunc);
     if (!f) return;  // read-only location: tune again next time
-    f << "rmr-tune 7 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << "\n";
+    f << "rmr-tune 8 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << ' ' << plan_signature() << "\n";
     for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
 }
 
@@ -488,6 +531,10 @@ ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
         a.res = hptr(op.res);
         a.res_cs = op.res.cs;
         a.res_co = op.res.co;
+    }
+    if (op.pre.c) {
+        a.pre = fptr(op.pre);
+        a.pre_cs = op.pre.cs;
     }
     a.Cout_pad = cw.cout_pad;
     a.K = cw.K;

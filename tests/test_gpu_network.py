@@ -260,3 +260,23 @@ def test_first_layer_sampling_the_frames_equals_letterbox_then_network(rmr, pack
         det.close()
     assert np.isfinite(out[0]).all()
     assert np.array_equal(out[0], out[1])
+
+
+def test_upsample_folded_into_the_next_1x1_equals_the_upsample_kernel(rmr, packs, refs, images, oracle, monkeypatch):
+    """conv1x1(concat[up2x(U), S]) = SiLU(W_S.S + b + up2x(W_U.U)): the planner computes the U half at
+    a quarter of the pixels in f32 and adds it in the S half's epilogue (ConvArgs::pre).  With
+    RMR_FUSE_UP=0 the upsample kernel writes the concat buffer as Ultralytics' graph does.  Same
+    function, different f32 summation order: both within the f16 floor of the oracle and of each
+    other."""
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    want = refs["armor"][1].forward(blobs)
+    out = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("RMR_FUSE_UP", fold)
+        det = rmr.Detector(packs[1], 12, (2592, 2048), 3, conf_thresh=0.5)
+        got, _ = det.infer(images)
+        _check_head(got, want, 2.0, 1e-2)
+        out.append(got)
+        det.close()
+    _check_head(out[0], out[1], 2.0, 1e-2)
+    assert not np.array_equal(out[0], out[1])  # the two plans really are different programs
