@@ -156,6 +156,9 @@ static void fill_descs(const std::vector<FrameStage::Frame>& fr, const int* crop
         if (d.crop_x < 0 || d.crop_y < 0 || d.crop_w <= 0 || d.crop_h <= 0 || d.crop_x + d.crop_w > fr[i].width ||
             d.crop_y + d.crop_h > fr[i].height)
             fail(RMR_ERR_INVALID_ARGUMENT, "image %d: crop outside the image", i);
+        // the sampling kernels address a frame with 32-bit byte offsets
+        if ((unsigned long long)fr[i].stride * (unsigned long long)fr[i].height >= 0xfffffff0ull)
+            fail(RMR_ERR_CAPACITY, "image %d: frames of 4 GiB or more are not supported", i);
     }
 }
 
