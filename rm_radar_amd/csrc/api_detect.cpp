@@ -167,7 +167,7 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             RMR_HIP(hipMemsetAsync(dtiming.p, 0, 64, ctx.stream));
             a.timing = dtiming.p;
         }
-        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..: conv_ws_s2 variant
+        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..: conv_pw variant
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
         } else if (tile >= 1000) {
@@ -186,6 +186,10 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             launch_conv_dma(ctx, ctx.stream, a, t);
             launch_conv_dma(ctx, ctx.stream, a, t);  // twice: the counters must re-arm themselves
             RMR_HIP(hipStreamSynchronize(ctx.stream));
+        } else if (tile >= 700) {
+            if (!conv_pw_supported(a, tile - 700))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: pointwise variant %d cannot run this layer", tile - 700);
+            launch_conv_pw(ctx, ctx.stream, a, tile - 700);
         } else if (tile >= 600) {
             if (!conv_ws_s2_supported(a, tile - 600))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: stride-2 weights-stationary variant %d cannot run this layer", tile - 600);

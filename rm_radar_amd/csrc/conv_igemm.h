@@ -78,6 +78,12 @@ int conv_direct_num_tiles();
 ConvTile conv_direct_tile(int id);
 bool conv_direct_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_direct(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+// pointwise layers with K = 96 / 192 / 384 and N = 96 / 192 (conv_pw.hip): weights stationary in
+// registers, persistent walk over the pixels through an LDS-DMA ring
+int conv_pw_num_variants();
+bool conv_pw_supported(const ConvArgs& a, int variant);  // variant < 0: any
+void launch_conv_pw(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant);
+
 // the network's first layer (conv_stem.hip): 3x3 / stride 2, 8 stored -> 48 channels, an HBM stream
 bool conv_stem_supported(const ConvArgs& a);
 void launch_conv_stem(DeviceCtx& ctx, hipStream_t stream, ConvArgs a);

@@ -1,0 +1,320 @@
+// conv_pw.hip -- pointwise (1x1 / stride 1) convolution with the weights stationary in registers and a
+// persistent walk over the pixels.
+//
+// The 1x1 layers of the 160x160 and 80x80 levels have K = 96..576 and N = 96..192: 2-18 K slices per
+// output tile.  In the tiled kernels (conv_dma) such a tile is all prologue and epilogue -- fill the
+// ring, a handful of MFMAs, drain -- and every tile pulls the whole 18-147 KB weight matrix through
+// the per-CU load path again (27 % of a 256 x 96 tile's bytes at K = 96).  They run at 2.5-3.3 TB/s
+// of algorithmic traffic where an HBM stream can do 4+.  Here instead:
+//
+//   * one workgroup per CU owns ALL output channels; wave (wm, wn) keeps the B fragments of its 48
+//     channels for the whole K in registers (K / 32 x 3 fragments = 36..144 VGPRs), loaded once;
+//   * the workgroup walks row blocks of BM pixels (block b, b + G, b + 2G, ...): the input is one
+//     continuous stream of stages, a stage = BM rows x 96 channels, DMA'd (buffer_load ... lds) into a
+//     ring STAGES deep with counted vmcnt waits, so the next blocks' reads are in flight under the
+//     MFMAs and the epilogue of the current one -- no per-tile pipeline fill;
+//   * a stage is three sub-slices of 64-byte rows in conv_dma's layout (source-side chunk swizzle
+//     {0,2,3,1}[row >> 2]: conflict-free ds_read_b128 fragment reads); one barrier per stage,
+//     36 x MREP / 4 MFMAs per wave between barriers, A fragments are the only LDS reads;
+//   * the epilogue (bias, SiLU, f16) runs every K / 96 stages and leaves through bounds-checked buffer
+//     stores, which are always issued (rows past M get an out-of-range offset): loads and stores
+//     retire in order on gfx9, so the stores of recent epilogues are simply part of the counted wait.
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "conv_igemm.h"
+
+namespace rmr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int PW_SPS = 3;  // K steps of 32 per stage
+constexpr int PW_NREP = 3; // 16-channel tiles per wave
+
+__device__ __forceinline__ float silu_p(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+__device__ __forceinline__ void dma16p(u32x4 rsrc, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmp() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is 6 bits");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+// epilogues among the STAGES - 1 stages before the one at position p of a block of E stages
+constexpr int pw_recent_epilogues(int p, int E, int stages) {
+    int c = 0;
+    for (int k = 1; k <= stages - 1; ++k)
+        if ((((p - k) % E) + E) % E == E - 1) ++c;
+    return c;
+}
+
+template <int KS, int WM, int WN, int MREP, int STAGES, bool OUT32>
+__global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, const int n_blocks) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * MREP * 16;
+    constexpr int E = KS / PW_SPS;            // stages per row block
+    constexpr int SSB = BM * 64;              // bytes of one sub-slice (BM rows x 32 channels)
+    constexpr int STAGE_BYTES = PW_SPS * SSB;
+    constexpr int NINST = STAGE_BYTES / 1024; // DMA instructions per stage
+    constexpr int NI = NINST / NW;            // per wave
+    constexpr int NST = MREP * PW_NREP;       // stores per wave per epilogue
+    static_assert(KS % PW_SPS == 0 && NINST % NW == 0, "stage geometry");
+    static_assert(STAGES >= 2 && STAGES <= 4 && E <= 6, "ring depth / stages per block");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, kg = lane >> 4;
+    const int fkey = (0x78 >> (2 * ((frow >> 2) & 3))) & 3;  // conv_dma's 64-byte-row swizzle key
+
+    const int G = gridDim.x;
+    const int w = blockIdx.x;
+    const int nb = w < n_blocks ? (n_blocks - w + G - 1) / G : 0;  // row blocks w, w + G, ...
+
+    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
+                           sgpr(a.in_bytes), sgpr(0x00020000u)};
+    const unsigned scratch = sgpr(lds0 + STAGES * STAGE_BYTES);
+    void* const outp = OUT32 ? (void*)a.out32 : (void*)a.out;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, 0xfffffff0u, 0x00020000);
+
+    // ---- the filter: B fragments of this wave's 48 channels, all K -----------------------------
+    half8 wreg[KS][PW_NREP];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < PW_NREP; ++j)
+            wreg[ks][j] = *(const half8*)((const _Float16*)a.wt + (size_t)(wn * 48 + j * 16 + frow) * a.Kp + ks * 32 + kg * 8);
+    const int cq = kg * 4;
+    float4 bias[PW_NREP];
+#pragma unroll
+    for (int j = 0; j < PW_NREP; ++j) bias[j] = *(const float4*)(a.bias + wn * 48 + j * 16 + cq);
+    // opaque from here on (no rematerialisation from memory inside the walk); this also waits for them,
+    // so no compiler-tracked load is outstanding once the hand-counted DMA starts
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < PW_NREP; ++j) asm volatile("" : "+v"(wreg[ks][j]));
+#pragma unroll
+    for (int j = 0; j < PW_NREP; ++j) asm volatile("" : "+v"(bias[j].x), "+v"(bias[j].y), "+v"(bias[j].z), "+v"(bias[j].w));
+
+    // ---- DMA bookkeeping: instruction q = wave + NW j of a stage -> sub-slice q / (BM/16), rows
+    // 16 (q % (BM/16)) + lane / 4, physical chunk lane % 4 holds logical chunk (lane % 4) ^ key(row)
+    int d_row[NI];
+    unsigned d_off[NI], d_dst[NI];
+    {
+        const int r16 = lane >> 2;
+        const int lchunk = (lane & 3) ^ ((0x78 >> (2 * ((r16 >> 2) & 3))) & 3);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int q = wave + NW * j;
+            const int sub = q / (BM / 16), rblk = q % (BM / 16);
+            d_row[j] = rblk * 16 + r16;
+            d_off[j] = (unsigned)(d_row[j] * a.in_cs + a.in_co + sub * 32 + lchunk * 8) * 2u;
+            d_dst[j] = (unsigned)(q * 1024);
+        }
+    }
+    int i_blk = 0, i_pos = 0;  // block / position of the next stage to issue
+    auto issue = [&](int slot) {
+        const bool live = i_blk < nb;  // wave-uniform; past the end: no-ops keep the counts constant
+        const int m0 = (w + i_blk * G) * BM;
+        const unsigned base = (unsigned)(m0 * a.in_cs + i_pos * (PW_SPS * 32)) * 2u;
+        const unsigned dead = live ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const unsigned off = (d_off[j] + base) | dead | (m0 + d_row[j] < a.M ? 0u : 0xffffffffu);
+            dma16p(in_rsrc, sgpr(lds0 + slot * STAGE_BYTES + d_dst[j]), off);
+        }
+        if (++i_pos == E) i_pos = 0, ++i_blk;
+    };
+
+    // prologue: STAGES - 1 stages in flight.  In steady state the stores of epilogue u sit right after
+    // the DMA of stage u + STAGES - 1; stand-ins (no-op loads) take the place of the epilogues "before
+    // the first stage", so that the counted waits below hold from the first stage on
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+        issue(s);
+        if ((((s - STAGES + 1) % E) + E) % E == E - 1) {
+#pragma unroll
+            for (int k = 0; k < NST; ++k) dma16p(in_rsrc, scratch, 0xffffffffu);
+        }
+    }
+
+    const unsigned a_base = (unsigned)((wm * MREP * 16 + frow) * 64 + ((kg ^ fkey) * 16));
+    const int px = frow;
+    // output offsets of this lane's MREP x 3 pieces within a row block (elements)
+    const unsigned elt = OUT32 ? 4u : 2u;
+
+    floatx4 acc[MREP][PW_NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < PW_NREP; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    int slot = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int m0 = (w + b * G) * BM;
+#pragma unroll
+        for (int p = 0; p < E; ++p) {
+            // this wave's share of the stage has landed once only the newer DMAs and the stores of the
+            // epilogues issued since may still be outstanding (in-order retirement)
+            switch (p) {  // p is a constant after unrolling; the template argument must be one before
+                case 0: wait_vmp<(STAGES - 2) * NI + NST * pw_recent_epilogues(0, E, STAGES)>(); break;
+                case 1: wait_vmp<(STAGES - 2) * NI + NST * pw_recent_epilogues(1 % E, E, STAGES)>(); break;
+                case 2: wait_vmp<(STAGES - 2) * NI + NST * pw_recent_epilogues(2 % E, E, STAGES)>(); break;
+                default: wait_vmp<(STAGES - 2) * NI + NST * pw_recent_epilogues(3 % E, E, STAGES)>(); break;  // p >= 3 >= STAGES - 1: none
+            }
+            __builtin_amdgcn_s_barrier();  // every wave's share; and the previous stage is fully consumed
+            {
+                int nxt = slot + STAGES - 1;
+                if (nxt >= STAGES) nxt -= STAGES;
+                issue(nxt);
+            }
+            const unsigned char* const sp = smem + slot * STAGE_BYTES + a_base;
+#pragma unroll
+            for (int ss = 0; ss < PW_SPS; ++ss) {
+                half8 xf[MREP];
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) xf[i] = *(const half8*)(sp + ss * SSB + i * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < PW_NREP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[p * PW_SPS + ss][j], xf[i], acc[i][j], 0, 0, 0);
+            }
+            if (++slot == STAGES) slot = 0;
+            if (p == E - 1) {
+                // ---- epilogue of the row block: bias, SiLU, store 4 consecutive channels per lane ----
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) {
+                    const int m = m0 + (wm * MREP + i) * 16 + px;
+                    const unsigned dead = m < a.M ? 0u : 0xffffffffu;
+                    const unsigned rowoff = (unsigned)(m * a.out_cs + a.out_co + wn * 48 + cq) * elt;
+#pragma unroll
+                    for (int j = 0; j < PW_NREP; ++j) {
+                        float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
+                                      acc[i][j][3] + bias[j].w};
+                        if (a.act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = silu_p(v[e]);
+                        }
+                        const unsigned off = (rowoff + (unsigned)(j * 16) * elt) | dead;
+                        if (OUT32) {
+                            u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
+                        } else {
+                            union {
+                                u32x2 u;
+                                _Float16 h[4];
+                            } o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o.h[e] = (_Float16)v[e];
+                            __builtin_amdgcn_raw_buffer_store_b64(o.u, out_rsrc, off, 0, 0);
+                        }
+                        acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        }
+    }
+    wait_vmp<0>();  // the trailing no-op DMAs must not outlive the workgroup's LDS
+}
+
+struct PwVariant {
+    int ks, n, bm, stages, threads, lds_bytes;
+    void (*k16)(const ConvArgs, int);
+    void (*k32)(const ConvArgs, int);
+};
+
+#define PWV(KS, WM, WN, MR, ST)                                                                  \
+    {                                                                                            \
+        KS, WN * 48, WM* MR * 16, ST, WM* WN * 64, ST * 3 * (WM * MR * 16) * 64 + 1024,          \
+            conv_pw_kernel<KS, WM, WN, MR, ST, false>, conv_pw_kernel<KS, WM, WN, MR, ST, true>  \
+    }
+
+const PwVariant kPw[] = {
+    PWV(3, 4, 2, 2, 4),   // 0: K  96, N  96, 128-row blocks
+    PWV(3, 4, 2, 4, 3),   // 1: K  96, N  96, 256-row blocks
+    PWV(6, 4, 2, 2, 4),   // 2: K 192, N  96, 128
+    PWV(6, 4, 2, 4, 3),   // 3: K 192, N  96, 256
+    PWV(6, 2, 4, 4, 4),   // 4: K 192, N 192, 128
+    PWV(6, 2, 4, 4, 3),   // 5: K 192, N 192, 128, shallower ring (two workgroups per CU)
+    PWV(12, 2, 4, 4, 4),  // 6: K 384, N 192, 128
+    PWV(12, 2, 4, 4, 3),  // 7: K 384, N 192, 128, shallower ring
+    PWV(3, 4, 2, 2, 3),   // 8: K  96, N  96, 128, shallower ring
+    PWV(6, 4, 2, 2, 3),   // 9: K 192, N  96, 128, shallower ring
+    PWV(18, 1, 4, 4, 4),  // 10: K 576, N 192, 64-row blocks, 4 waves (216 VGPRs of weights: one wave per SIMD)
+    PWV(12, 1, 4, 4, 4),  // 11: K 384, N 192, the same layout
+};
+constexpr int kNumPw = sizeof(kPw) / sizeof(kPw[0]);
+
+}  // namespace
+
+int conv_pw_num_variants() { return kNumPw; }
+
+bool conv_pw_supported(const ConvArgs& a, int variant) {
+    if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.res || a.pre || a.split > 1 || a.Cin != a.K || a.K % 96 || a.Kp < a.K || a.in_bytes == 0) return false;
+    if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 || (!a.out && !a.out32)) return false;
+    // 32-bit byte offsets into the views
+    if ((double)a.M * a.out_cs * (a.out32 ? 4 : 2) >= 4.0e9 || (double)a.M * a.in_cs * 2 >= 4.0e9) return false;
+    if (variant < 0) {
+        for (int v = 0; v < kNumPw; ++v)
+            if (kPw[v].ks * 32 == a.K && kPw[v].n == a.Cout_pad) return true;
+        return false;
+    }
+    return variant < kNumPw && kPw[variant].ks * 32 == a.K && kPw[variant].n == a.Cout_pad;
+}
+
+void launch_conv_pw(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant) {
+    if (!conv_pw_supported(a, variant)) fail(RMR_ERR_LOGIC, "conv_pw: variant %d cannot run this layer", variant);
+    const PwVariant& v = kPw[variant];
+    const int n_blocks = (a.M + v.bm - 1) / v.bm;
+    // persistent: one workgroup per CU, two where the ring leaves room
+    const int per_cu = v.lds_bytes <= 80 * 1024 ? 2 : 1;
+    const int grid = std::min(n_blocks, ctx.num_cus * per_cu);
+    const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
+    const double bytes = 2.0 * ((double)a.M * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
+    static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
+    static std::mutex name_mu;
+    static std::map<std::string, std::string> names;
+    const char* pname = "conv_igemm_f16";
+    if (per_layer && ctx.prof.on) {
+        char buf[48];
+        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k1 s1 p%d", a.M, a.Cout_pad, a.K, variant);
+        std::lock_guard<std::mutex> lk(name_mu);
+        pname = names.emplace(buf, buf).first->second.c_str();
+    }
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        for (const PwVariant& pv : kPw) {
+            (void)hipFuncSetAttribute((const void*)pv.k16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)pv.k32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+    });
+    ProfScope ps(ctx.prof, stream, pname, flops, bytes);
+    if (a.out32)
+        v.k32<<<grid, v.threads, v.lds_bytes, stream>>>(a, n_blocks);
+    else
+        v.k16<<<grid, v.threads, v.lds_bytes, stream>>>(a, n_blocks);
+    RMR_HIP(hipGetLastError());
+}
+
+}  // namespace rmr

@@ -360,7 +360,9 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
 // (layer, batch) -- the analogue of the reference's TensorRT engine build (detector.cpp:177-243).
 void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     const int split = choice / 1000, c = choice % 1000;
-    if (c >= 600) {
+    if (c >= 700) {
+        launch_conv_pw(ctx_, s, a, c - 700);
+    } else if (c >= 600) {
         launch_conv_ws_s2(ctx_, s, a, c - 600);
     } else if (c == 500) {
         launch_conv_stem(ctx_, s, a);
@@ -399,6 +401,9 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (conv_direct_supported(a, -1) && a.M <= 64 * ctx_.num_cus)
         for (int t = 0; t < conv_direct_num_tiles(); ++t)
             if (conv_direct_supported(a, t)) cands.push_back(400 + t);
+    if (conv_pw_supported(a, -1))
+        for (int v = 0; v < conv_pw_num_variants(); ++v)
+            if (conv_pw_supported(a, v)) cands.push_back(700 + v);
     if (!a.pre && conv_ws_s2_supported(a, -1))
         for (int v = 0; v < conv_ws_s2_num_variants(); ++v)
             if (conv_ws_s2_supported(a, v)) cands.push_back(600 + v);
@@ -477,14 +482,15 @@ void Yolov8::load_tuning() {
     int version = 0, n_ops = 0, w = 0, h = 0;
     unsigned long long sig = 0;
     f >> tag >> version >> n_ops >> w >> h >> sig;
-    if (tag != "rmr-tune" || version != 8 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_ || sig != plan_signature())
+    if (tag != "rmr-tune" || version != 9 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_ || sig != plan_signature())
         return;
     int op, n, choice;
     while (f >> op >> n >> choice) {
         if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV) continue;
         const int c = choice % 1000, split = choice / 1000;
         const bool ok = choice >= 0 && split <= 64 && (split == 0 || (c >= 100 && c < 200)) &&
-                        (c >= 600 ? c - 600 < conv_ws_s2_num_variants()
+                        (c >= 700 ? c - 700 < conv_pw_num_variants()
+                         : c >= 600 ? c - 600 < conv_ws_s2_num_variants()
                          : c == 500 ? true
                          : c >= 400 ? c - 400 < conv_direct_num_tiles()
                          : c >= 300 ? c - 300 < conv_ws_num_variants()
@@ -497,7 +503,7 @@ void Yolov8::load_tuning() {
 void Yolov8::save_tuning() {
     std::ofstream f(tune_path_, std::ios::trunc);
     if (!f) return;  // read-only location: tune again next time
-    f << "rmr-tune 8 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << ' ' << plan_signature() << "\n";
+    f << "rmr-tune 9 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << ' ' << plan_signature() << "\n";
     for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
 }
 

@@ -216,6 +216,29 @@ def test_conv_ws_stride2(rmr):
                    False, tile=600)  # stride 1
 
 
+def test_conv_pointwise_weights_stationary(rmr):
+    # conv_pw.hip (ids 700..): 1x1 layers with K = 96 / 192 / 384 / 576, N = 96 / 192; the filter stays in
+    # registers and each workgroup walks many row blocks through a DMA ring whose waits count the
+    # stores of recent epilogues.  Ragged M (the last block is partly out of range), fewer blocks than
+    # ring stages, and more blocks than workgroups (the persistent walk proper, several blocks per CU).
+    shapes = {0: (96, 96), 1: (96, 96), 8: (96, 96), 2: (192, 96), 3: (192, 96), 9: (192, 96), 4: (192, 192),
+              5: (192, 192), 6: (384, 192), 7: (384, 192), 10: (576, 192), 11: (384, 192)}
+    for v, (k, n) in shapes.items():
+        run_case(rmr, 2, 13, 11, k, n, 1, 1, True, False, tile=700 + v, seed=180 + v)        # 286 rows: 2-3 blocks
+        run_case(rmr, 1, 5, 7, k, n - 7, 1, 1, False, False, tile=700 + v, seed=190 + v)     # one partial block, padded channels
+    run_case(rmr, 2, 240, 200, 96, 96, 1, 1, True, False, tile=700, seed=200)    # 750 blocks of 128 over 512 workgroups
+    run_case(rmr, 1, 300, 257, 96, 96, 1, 1, True, False, tile=701, seed=201)    # 302 blocks of 256, ragged
+    run_case(rmr, 1, 250, 200, 192, 192, 1, 1, True, False, tile=704, seed=202)  # 391 blocks, two stages per block
+    run_case(rmr, 1, 200, 180, 384, 192, 1, 1, True, False, tile=706, seed=203)  # 282 blocks, four stages per block
+    run_case(rmr, 1, 160, 130, 576, 192, 1, 1, True, False, tile=710, seed=204)  # 325 blocks of 64, six stages per block
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 8, 96), np.float32), np.zeros((96, 96, 3, 3), np.float32), None, 1, 1,
+                   False, tile=700)  # 3x3
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 8, 192), np.float32), np.zeros((96, 192, 1, 1), np.float32), None, 1, 0,
+                   False, tile=700)  # variant 0 is K = 96
+
+
 def test_conv_matches_c_oracle(rmr, oracle):
     # the plain-C direct convolution (oracle/rmr_oracle.c) agrees with both
     rng = np.random.default_rng(5)
