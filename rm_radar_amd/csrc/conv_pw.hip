@@ -1,7 +1,7 @@
 // conv_pw.hip -- pointwise (1x1 / stride 1) convolution with the weights stationary in registers and a
 // persistent walk over the pixels.
 //
-// The 1x1 layers of the 160x160 and 80x80 levels have K = 96..576 and N = 96..192: 2-18 K slices per
+// The 1x1 layers of the 160x160 .. 40x40 levels have K = 96..768 and N = 96..384: 2-24 K slices per
 // output tile.  In the tiled kernels (conv_dma) such a tile is all prologue and epilogue -- fill the
 // ring, a handful of MFMAs, drain -- and every tile pulls the whole 18-147 KB weight matrix through
 // the per-CU load path again (27 % of a 256 x 96 tile's bytes at K = 96).  They run at 2.5-3.3 TB/s
@@ -16,7 +16,7 @@
 //   * a stage is three sub-slices of 64-byte rows in conv_dma's layout (source-side chunk swizzle
 //     {0,2,3,1}[row >> 2]: conflict-free ds_read_b128 fragment reads); one barrier per stage,
 //     36 x MREP / 4 MFMAs per wave between barriers, A fragments are the only LDS reads;
-//   * the epilogue (bias, SiLU, f16) runs every K / 96 stages and leaves through bounds-checked buffer
+//   * the epilogue (bias, optional half-resolution addend, SiLU, f16) runs every K / 96 stages and leaves through bounds-checked buffer
 //     stores, which are always issued (rows past M get an out-of-range offset): loads and stores
 //     retire in order on gfx9, so the stores of recent epilogues are simply part of the counted wait.
 #include <cstdlib>
@@ -61,8 +61,9 @@ constexpr int pw_recent_epilogues(int p, int E, int stages) {
     return c;
 }
 
-template <int KS, int WM, int WN, int MREP, int STAGES, bool OUT32>
-__global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, const int n_blocks) {
+// MODE 0: f16 output; 1: f32 output; 2: f16 output with the half-resolution f32 addend (ConvArgs::pre)
+template <int KS, int WM, int WN, int MREP, int STAGES, int MODE>
+__global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, const int n_blocks, const int n_tiles) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 16;
     constexpr int E = KS / PW_SPS;            // stages per row block
@@ -71,8 +72,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
     constexpr int NINST = STAGE_BYTES / 1024; // DMA instructions per stage
     constexpr int NI = NINST / NW;            // per wave
     constexpr int NST = MREP * PW_NREP;       // stores per wave per epilogue
+    constexpr bool OUT32 = MODE == 1, PRE = MODE == 2;
     static_assert(KS % PW_SPS == 0 && NINST % NW == 0, "stage geometry");
-    static_assert(STAGES >= 2 && STAGES <= 4 && E <= 6, "ring depth / stages per block");
+    static_assert(STAGES >= 2 && STAGES <= 4 && E <= 8, "ring depth / stages per block");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -85,8 +87,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
     const int frow = lane & 15, kg = lane >> 4;
     const int fkey = (0x78 >> (2 * ((frow >> 2) & 3))) & 3;  // conv_dma's 64-byte-row swizzle key
 
-    const int G = gridDim.x;
-    const int w = blockIdx.x;
+    // n_tiles workgroups (channel tiles of WN x 48) walk the same row blocks side by side; ids are dealt
+    // round-robin to the 8 XCDs, so the tiles of one walker are 8 ids apart: same XCD, same L2
+    const int G = gridDim.x / n_tiles;  // walkers (a multiple of 8 unless there is only one channel tile)
+    const int nt = n_tiles > 1 ? (int)(blockIdx.x >> 3) % n_tiles : 0;
+    const int w = n_tiles > 1 ? (int)((blockIdx.x >> 3) / n_tiles) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
+    const int nbase = nt * (WN * 48) + wn * 48;  // this wave's first output channel
     const int nb = w < n_blocks ? (n_blocks - w + G - 1) / G : 0;  // row blocks w, w + G, ...
 
     const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
@@ -94,6 +100,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
     const unsigned scratch = sgpr(lds0 + STAGES * STAGE_BYTES);
     void* const outp = OUT32 ? (void*)a.out32 : (void*)a.out;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, 0xfffffff0u, 0x00020000);
+    const u32x4 pre_rsrc = {sgpr((unsigned)(size_t)a.pre), sgpr((unsigned)((size_t)a.pre >> 32) & 0xffffu),
+                            sgpr(0xfffffff0u), sgpr(0x00020000u)};
+    const int hw = a.Ho * a.Wo;
+    const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)a.Wo;
 
     // ---- the filter: B fragments of this wave's 48 channels, all K -----------------------------
     half8 wreg[KS][PW_NREP];
@@ -101,11 +111,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < PW_NREP; ++j)
-            wreg[ks][j] = *(const half8*)((const _Float16*)a.wt + (size_t)(wn * 48 + j * 16 + frow) * a.Kp + ks * 32 + kg * 8);
+            wreg[ks][j] = *(const half8*)((const _Float16*)a.wt + (size_t)(nbase + j * 16 + frow) * a.Kp + ks * 32 + kg * 8);
     const int cq = kg * 4;
     float4 bias[PW_NREP];
 #pragma unroll
-    for (int j = 0; j < PW_NREP; ++j) bias[j] = *(const float4*)(a.bias + wn * 48 + j * 16 + cq);
+    for (int j = 0; j < PW_NREP; ++j) bias[j] = *(const float4*)(a.bias + nbase + j * 16 + cq);
     // opaque from here on (no rematerialisation from memory inside the walk); this also waits for them,
     // so no compiler-tracked load is outstanding once the hand-counted DMA starts
 #pragma unroll
@@ -182,6 +192,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
                 default: wait_vmp<(STAGES - 2) * NI + NST * pw_recent_epilogues(3 % E, E, STAGES)>(); break;  // p >= 3 >= STAGES - 1: none
             }
             __builtin_amdgcn_s_barrier();  // every wave's share; and the previous stage is fully consumed
+            floatx4 tpre[MREP][PW_NREP];
+            if (PRE && p == E - 1) {
+                // the block's addends, issued BEFORE this stage's DMA: the epilogue then waits for
+                // everything but that newest DMA (in-order retirement), i.e. for data requested a
+                // stage of MFMAs ago at the least
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) {
+                    const int m = m0 + (wm * MREP + i) * 16 + px;
+                    // m -> (image, y, x) with float reciprocals and a one-step correction (m < 2^24)
+                    int img = (int)((float)m * inv_hw);
+                    img += (img + 1) * hw <= m ? 1 : 0;
+                    img -= img * hw > m ? 1 : 0;
+                    const int rem = m - img * hw;
+                    int y = (int)((float)rem * inv_w);
+                    y += (y + 1) * a.Wo <= rem ? 1 : 0;
+                    y -= y * a.Wo > rem ? 1 : 0;
+                    const int x = rem - y * a.Wo;
+                    const int mpre = (img * (a.Ho >> 1) + (y >> 1)) * (a.Wo >> 1) + (x >> 1);
+                    const unsigned rowoff = (unsigned)(mpre * a.pre_cs + nbase + cq) * 4u;
+                    const unsigned dead = m < a.M ? 0u : 0xffffffffu;
+#pragma unroll
+                    for (int j = 0; j < PW_NREP; ++j)
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen"
+                                     : "=&v"(tpre[i][j])
+                                     : "v"((rowoff + (unsigned)(j * 64)) | dead), "s"(pre_rsrc)
+                                     : "memory");
+                }
+            }
             {
                 int nxt = slot + STAGES - 1;
                 if (nxt >= STAGES) nxt -= STAGES;
@@ -202,15 +240,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
             if (++slot == STAGES) slot = 0;
             if (p == E - 1) {
                 // ---- epilogue of the row block: bias, SiLU, store 4 consecutive channels per lane ----
+                if (PRE) {
+                    wait_vmp<NI>();
+#pragma unroll
+                    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                        for (int j = 0; j < PW_NREP; ++j) asm volatile("" : "+v"(tpre[i][j]));  // uses stay below the wait
+                }
 #pragma unroll
                 for (int i = 0; i < MREP; ++i) {
                     const int m = m0 + (wm * MREP + i) * 16 + px;
                     const unsigned dead = m < a.M ? 0u : 0xffffffffu;
-                    const unsigned rowoff = (unsigned)(m * a.out_cs + a.out_co + wn * 48 + cq) * elt;
+                    const unsigned rowoff = (unsigned)(m * a.out_cs + a.out_co + nbase + cq) * elt;
 #pragma unroll
                     for (int j = 0; j < PW_NREP; ++j) {
                         float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
                                       acc[i][j][3] + bias[j].w};
+                        if (PRE) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += tpre[i][j][e];
+                        }
                         if (a.act) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = silu_p(v[e]);
@@ -239,14 +288,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
 
 struct PwVariant {
     int ks, n, bm, stages, threads, lds_bytes;
-    void (*k16)(const ConvArgs, int);
-    void (*k32)(const ConvArgs, int);
+    void (*k16)(const ConvArgs, int, int);
+    void (*k32)(const ConvArgs, int, int);
+    void (*kpre)(const ConvArgs, int, int);  // null: the variant has no registers to spare for the addend
 };
 
 #define PWV(KS, WM, WN, MR, ST)                                                                  \
     {                                                                                            \
         KS, WN * 48, WM* MR * 16, ST, WM* WN * 64, ST * 3 * (WM * MR * 16) * 64 + 1024,          \
-            conv_pw_kernel<KS, WM, WN, MR, ST, false>, conv_pw_kernel<KS, WM, WN, MR, ST, true>  \
+            conv_pw_kernel<KS, WM, WN, MR, ST, 0>, conv_pw_kernel<KS, WM, WN, MR, ST, 1>, nullptr \
+    }
+#define PWV_PRE(KS, WM, WN, MR, ST)                                                              \
+    {                                                                                            \
+        KS, WN * 48, WM* MR * 16, ST, WM* WN * 64, ST * 3 * (WM * MR * 16) * 64 + 1024,          \
+            conv_pw_kernel<KS, WM, WN, MR, ST, 0>, conv_pw_kernel<KS, WM, WN, MR, ST, 1>,        \
+            conv_pw_kernel<KS, WM, WN, MR, ST, 2>                                                \
     }
 
 const PwVariant kPw[] = {
@@ -254,14 +310,15 @@ const PwVariant kPw[] = {
     PWV(3, 4, 2, 4, 3),   // 1: K  96, N  96, 256-row blocks
     PWV(6, 4, 2, 2, 4),   // 2: K 192, N  96, 128
     PWV(6, 4, 2, 4, 3),   // 3: K 192, N  96, 256
-    PWV(6, 2, 4, 4, 4),   // 4: K 192, N 192, 128
-    PWV(6, 2, 4, 4, 3),   // 5: K 192, N 192, 128, shallower ring (two workgroups per CU)
+    PWV_PRE(6, 2, 4, 4, 4),   // 4: K 192, N 192, 128
+    PWV_PRE(6, 2, 4, 4, 3),   // 5: K 192, N 192, 128, shallower ring (two workgroups per CU)
     PWV(12, 2, 4, 4, 4),  // 6: K 384, N 192, 128
     PWV(12, 2, 4, 4, 3),  // 7: K 384, N 192, 128, shallower ring
     PWV(3, 4, 2, 2, 3),   // 8: K  96, N  96, 128, shallower ring
     PWV(6, 4, 2, 2, 3),   // 9: K 192, N  96, 128, shallower ring
     PWV(18, 1, 4, 4, 4),  // 10: K 576, N 192, 64-row blocks, 4 waves (216 VGPRs of weights: one wave per SIMD)
-    PWV(12, 1, 4, 4, 4),  // 11: K 384, N 192, the same layout
+    PWV_PRE(12, 1, 4, 4, 4),  // 11: K 384, N 192, the same layout
+    PWV(24, 1, 4, 4, 4),  // 12: K 768, N 192 per workgroup (288 VGPRs of weights)
 };
 constexpr int kNumPw = sizeof(kPw) / sizeof(kPw[0]);
 
@@ -271,16 +328,21 @@ int conv_pw_num_variants() { return kNumPw; }
 
 bool conv_pw_supported(const ConvArgs& a, int variant) {
     if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.Ho != a.H || a.Wo != a.W) return false;
-    if (a.res || a.pre || a.split > 1 || a.Cin != a.K || a.K % 96 || a.Kp < a.K || a.in_bytes == 0) return false;
+    if (a.res || (a.pre && (a.out32 || a.Ho % 2 || a.Wo % 2 || a.M >= (1 << 24))) || a.split > 1 || a.Cin != a.K || a.K % 96 || a.Kp < a.K || a.in_bytes == 0) return false;
     if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 || (!a.out && !a.out32)) return false;
     // 32-bit byte offsets into the views
     if ((double)a.M * a.out_cs * (a.out32 ? 4 : 2) >= 4.0e9 || (double)a.M * a.in_cs * 2 >= 4.0e9) return false;
+    // a workgroup owns v.n channels; wider layers run 2-3 workgroups side by side on the same rows
+    const auto fits = [&](const PwVariant& v) {
+        return v.ks * 32 == a.K && a.Cout_pad % v.n == 0 && a.Cout_pad / v.n <= 3 && (a.Cout_pad == v.n || v.n == 192) &&
+               (!a.pre || v.kpre);
+    };
     if (variant < 0) {
         for (int v = 0; v < kNumPw; ++v)
-            if (kPw[v].ks * 32 == a.K && kPw[v].n == a.Cout_pad) return true;
+            if (fits(kPw[v])) return true;
         return false;
     }
-    return variant < kNumPw && kPw[variant].ks * 32 == a.K && kPw[variant].n == a.Cout_pad;
+    return variant < kNumPw && fits(kPw[variant]);
 }
 
 void launch_conv_pw(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant) {
@@ -289,7 +351,10 @@ void launch_conv_pw(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
     const int n_blocks = (a.M + v.bm - 1) / v.bm;
     // persistent: one workgroup per CU, two where the ring leaves room
     const int per_cu = v.lds_bytes <= 80 * 1024 ? 2 : 1;
-    const int grid = std::min(n_blocks, ctx.num_cus * per_cu);
+    const int n_tiles = a.Cout_pad / v.n;
+    int walkers = std::min(n_blocks, std::max(1, ctx.num_cus * per_cu / n_tiles));
+    if (n_tiles > 1) walkers = (walkers + 7) / 8 * 8;  // the id -> (walker, tile) map deals whole octets
+    const int grid = walkers * n_tiles;
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.M * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
     static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
@@ -307,13 +372,16 @@ void launch_conv_pw(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
         for (const PwVariant& pv : kPw) {
             (void)hipFuncSetAttribute((const void*)pv.k16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)pv.k32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (pv.kpre) (void)hipFuncSetAttribute((const void*)pv.kpre, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
     });
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
-    if (a.out32)
-        v.k32<<<grid, v.threads, v.lds_bytes, stream>>>(a, n_blocks);
+    if (a.pre)
+        v.kpre<<<grid, v.threads, v.lds_bytes, stream>>>(a, n_blocks, n_tiles);
+    else if (a.out32)
+        v.k32<<<grid, v.threads, v.lds_bytes, stream>>>(a, n_blocks, n_tiles);
     else
-        v.k16<<<grid, v.threads, v.lds_bytes, stream>>>(a, n_blocks);
+        v.k16<<<grid, v.threads, v.lds_bytes, stream>>>(a, n_blocks, n_tiles);
     RMR_HIP(hipGetLastError());
 }
 

@@ -424,6 +424,17 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
                 cands.push_back(1000 * split + 100 + t);
             }
         }
+    // RMR_TUNE_ONLY=lo-hi: layers that have candidates in that id range choose among those only (tests
+    // use it to pin a kernel family under the whole network, e.g. 700-799 = conv_pw)
+    if (const char* e = std::getenv("RMR_TUNE_ONLY")) {
+        int lo = 0, hi = 0;
+        if (sscanf(e, "%d-%d", &lo, &hi) == 2) {
+            std::vector<int> only;
+            for (int c : cands)
+                if (c % 1000 >= lo && c % 1000 <= hi && c < 1000) only.push_back(c);
+            if (!only.empty()) cands.swap(only);
+        }
+    }
     hipEvent_t e0, e1;
     RMR_HIP(hipEventCreate(&e0));
     RMR_HIP(hipEventCreate(&e1));

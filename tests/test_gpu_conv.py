@@ -231,6 +231,11 @@ def test_conv_pointwise_weights_stationary(rmr):
     run_case(rmr, 1, 250, 200, 192, 192, 1, 1, True, False, tile=704, seed=202)  # 391 blocks, two stages per block
     run_case(rmr, 1, 200, 180, 384, 192, 1, 1, True, False, tile=706, seed=203)  # 282 blocks, four stages per block
     run_case(rmr, 1, 160, 130, 576, 192, 1, 1, True, False, tile=710, seed=204)  # 325 blocks of 64, six stages per block
+    # layers wider than a workgroup's 192 channels: 2-3 workgroups walk the same rows side by side
+    run_case(rmr, 2, 13, 11, 768, 384, 1, 1, True, False, tile=712, seed=205)
+    run_case(rmr, 1, 150, 120, 768, 384, 1, 1, True, False, tile=712, seed=206)  # 282 blocks x 2 channel tiles, eight stages per block
+    run_case(rmr, 1, 130, 100, 384, 384, 1, 1, True, False, tile=706, seed=207)
+    run_case(rmr, 1, 9, 9, 576, 570, 1, 1, False, False, tile=710, seed=208)     # three channel tiles, padded channels
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 8, 8, 96), np.float32), np.zeros((96, 96, 3, 3), np.float32), None, 1, 1,
                    False, tile=700)  # 3x3

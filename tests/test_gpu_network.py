@@ -280,3 +280,25 @@ def test_upsample_folded_into_the_next_1x1_equals_the_upsample_kernel(rmr, packs
         det.close()
     _check_head(out[0], out[1], 2.0, 1e-2)
     assert not np.array_equal(out[0], out[1])  # the two plans really are different programs
+
+
+def test_network_on_the_pointwise_kernels(rmr, packs, refs, images, oracle, monkeypatch, tmp_path):
+    """conv_pw.hip under the whole network: RMR_TUNE_ONLY=700-799 makes every 1x1 layer it supports
+    (K 96..768, N 96..384, among them the two that carry the folded upsample's addend) run on it
+    whatever the autotuner would have preferred at this batch size; same oracle, same tolerance."""
+    import shutil
+    pack = str(tmp_path / "armor_pw.rmrw")  # its own tuning cache
+    shutil.copy(packs[1], pack)
+    monkeypatch.setenv("RMR_TUNE_ONLY", "700-799")
+    monkeypatch.setenv("RMR_TUNE_VERBOSE", "1")
+    n = 5
+    det = rmr.Detector(pack, 12, (2592, 2048), n, conf_thresh=0.5)
+    batch = [images[i % 3] for i in range(n)]
+    got, _ = det.infer(batch)
+    det.close()
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    want = refs["armor"][1].forward(blobs)
+    for i in range(n):
+        _check_head(got[i:i + 1], want[i % 3:i % 3 + 1], 2.0, 1e-2)
+    tuned = [l.split() for l in open(pack + ".tune").read().splitlines()[1:]]
+    assert sum(1 for t in tuned if 700 <= int(t[2]) < 800) >= 10
