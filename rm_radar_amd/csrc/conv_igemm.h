@@ -27,6 +27,12 @@ struct ConvArgs {
     // conv_dma only; Ho and Wo even)
     const float* pre;
     int pre_cs;
+    // planar channel groups ("slabs", conv_pw only; 0 = off): channel ch of the input lives in slab
+    // ch / in_slab_c at pixel pitch in_cs, slabs in_slab_stride BYTES apart; likewise the output.  A
+    // C2f keeps its chunks as slabs so that the 3x3 convs between its two 1x1 convs read and write
+    // contiguous rows instead of 96..192-byte slices of wide pixels (whole 128-byte lines travel)
+    int in_slab_c, out_slab_c;
+    unsigned in_slab_stride, out_slab_stride;
     int Cout_pad;       // multiple of the tile's BN
     int K, Kp, M;       // K = KH*KW*Cin, Kp = K rounded up to 64, M = N*Ho*Wo
     int act;            // 1 = SiLU

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
     // ---- DMA bookkeeping: instruction q = wave + NW j of a stage -> sub-slice q / (BM/16), rows
     // 16 (q % (BM/16)) + lane / 4, physical chunk lane % 4 holds logical chunk (lane % 4) ^ key(row)
     int d_row[NI];
-    unsigned d_off[NI], d_dst[NI];
+    unsigned d_off[E][NI], d_dst[NI];  // per position of the stage within its row block
     {
         const int r16 = lane >> 2;
         const int lchunk = (lane & 3) ^ ((0x78 >> (2 * ((r16 >> 2) & 3))) & 3);
@@ -137,22 +137,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
             const int q = wave + NW * j;
             const int sub = q / (BM / 16), rblk = q % (BM / 16);
             d_row[j] = rblk * 16 + r16;
-            d_off[j] = (unsigned)(d_row[j] * a.in_cs + a.in_co + sub * 32 + lchunk * 8) * 2u;
             d_dst[j] = (unsigned)(q * 1024);
+#pragma unroll
+            for (int pos = 0; pos < E; ++pos) {
+                const int ch = pos * (PW_SPS * 32) + sub * 32 + lchunk * 8;
+                const int slab = a.in_slab_c ? ch / a.in_slab_c : 0;
+                const int within = ch - slab * a.in_slab_c;
+                d_off[pos][j] = (unsigned)slab * a.in_slab_stride + (unsigned)(d_row[j] * a.in_cs + a.in_co + within) * 2u;
+            }
         }
     }
-    int i_blk = 0, i_pos = 0;  // block / position of the next stage to issue
-    auto issue = [&](int slot) {
+    int i_blk = 0;  // row block of the next stage to issue
+    auto issue = [&](int slot, const int pos) {  // pos: compile-time at every call site
         const bool live = i_blk < nb;  // wave-uniform; past the end: no-ops keep the counts constant
         const int m0 = (w + i_blk * G) * BM;
-        const unsigned base = (unsigned)(m0 * a.in_cs + i_pos * (PW_SPS * 32)) * 2u;
+        const unsigned base = (unsigned)(m0 * a.in_cs) * 2u;
         const unsigned dead = live ? 0u : 0xffffffffu;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const unsigned off = (d_off[j] + base) | dead | (m0 + d_row[j] < a.M ? 0u : 0xffffffffu);
+            const unsigned off = (d_off[pos][j] + base) | dead | (m0 + d_row[j] < a.M ? 0u : 0xffffffffu);
             dma16p(in_rsrc, sgpr(lds0 + slot * STAGE_BYTES + d_dst[j]), off);
         }
-        if (++i_pos == E) i_pos = 0, ++i_blk;
+        if (pos == E - 1) ++i_blk;
     };
 
     // prologue: STAGES - 1 stages in flight.  In steady state the stores of epilogue u sit right after
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
     // the first stage", so that the counted waits below hold from the first stage on
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) {
-        issue(s);
+        issue(s, s % E);
         if ((((s - STAGES + 1) % E) + E) % E == E - 1) {
 #pragma unroll
             for (int k = 0; k < NST; ++k) dma16p(in_rsrc, scratch, 0xffffffffu);
@@ -168,6 +174,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
     }
 
     const unsigned a_base = (unsigned)((wm * MREP * 16 + frow) * 64 + ((kg ^ fkey) * 16));
+    // this wave's 48 output channels lie in one slab
+    const int oslab = a.out_slab_c ? nbase / a.out_slab_c : 0;
+    const unsigned obase = (unsigned)oslab * a.out_slab_stride + (unsigned)(a.out_co + nbase - oslab * a.out_slab_c + (lane >> 4) * 4) * (OUT32 ? 4u : 2u);
     const int px = frow;
     // output offsets of this lane's MREP x 3 pieces within a row block (elements)
     const unsigned elt = OUT32 ? 4u : 2u;
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
             {
                 int nxt = slot + STAGES - 1;
                 if (nxt >= STAGES) nxt -= STAGES;
-                issue(nxt);
+                issue(nxt, (p + STAGES - 1) % E);
             }
             const unsigned char* const sp = smem + slot * STAGE_BYTES + a_base;
 #pragma unroll
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
                 for (int i = 0; i < MREP; ++i) {
                     const int m = m0 + (wm * MREP + i) * 16 + px;
                     const unsigned dead = m < a.M ? 0u : 0xffffffffu;
-                    const unsigned rowoff = (unsigned)(m * a.out_cs + a.out_co + nbase + cq) * elt;
+                    const unsigned rowoff = (unsigned)(m * a.out_cs) * elt + obase;
 #pragma unroll
                     for (int j = 0; j < PW_NREP; ++j) {
                         float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
@@ -330,8 +339,12 @@ bool conv_pw_supported(const ConvArgs& a, int variant) {
     if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.Ho != a.H || a.Wo != a.W) return false;
     if (a.res || (a.pre && (a.out32 || a.Ho % 2 || a.Wo % 2 || a.M >= (1 << 24))) || a.split > 1 || a.Cin != a.K || a.K % 96 || a.Kp < a.K || a.in_bytes == 0) return false;
     if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 || (!a.out && !a.out32)) return false;
+    if (a.in_slab_c % 8 || a.out_slab_c % 48) return false;  // 16-byte chunks / a wave's 48 channels stay within a slab
     // 32-bit byte offsets into the views
-    if ((double)a.M * a.out_cs * (a.out32 ? 4 : 2) >= 4.0e9 || (double)a.M * a.in_cs * 2 >= 4.0e9) return false;
+    const double in_span = (a.in_slab_c ? (double)(a.K / a.in_slab_c - 1) * a.in_slab_stride : 0.0) + (double)a.M * a.in_cs * 2;
+    const double out_span = (a.out_slab_c ? (double)(a.Cout_pad / a.out_slab_c - 1) * a.out_slab_stride : 0.0) +
+                            (double)a.M * a.out_cs * (a.out32 ? 4 : 2);
+    if (in_span >= 4.0e9 || out_span >= 4.0e9) return false;
     // a workgroup owns v.n channels; wider layers run 2-3 workgroups side by side on the same rows
     const auto fits = [&](const PwVariant& v) {
         return v.ks * 32 == a.K && a.Cout_pad % v.n == 0 && a.Cout_pad / v.n <= 3 && (a.Cout_pad == v.n || v.n == 192) &&

@@ -69,6 +69,10 @@ class Yolov8 {
         int conv = -1;      // index into convs_
         View in, out, res;  // res.c == 0 : none
         View pre;           // pre.c != 0: f32 half-resolution addend before the activation (ConvArgs::pre)
+        // planar channel groups (ConvArgs::in_slab_c ...): `in` / `out` is the first slab (cs = slab
+        // width, c = all channels), the others follow at equal distances of slab_step elements per image
+        int in_slab_c = 0, out_slab_c = 0;
+        size_t in_slab_step = 0, out_slab_step = 0;
         bool in_is_input = false;
         bool out_f32 = false;
         int stride = 1, act = 1;
@@ -90,6 +94,8 @@ class Yolov8 {
     View c2f(const WeightPack& p, const std::string& name, const View& x, int n, bool shortcut,
              const View* out_view, const View* up = nullptr);
     bool fuse_up_ = true;  // RMR_FUSE_UP=0: upsample kernel + cv1 over the concat
+    bool slabs_ = true;    // RMR_SLABS=0: every C2f keeps its chunks interleaved in one wide buffer
+    bool pw_can(int K, int N, int h, int w, bool pre) const;
     void run_op(hipStream_t s, int op_index, int chunk_n, size_t img_base);
     ConvArgs conv_args(int op_index, int chunk_n, size_t img_base);
     int tune_conv(hipStream_t s, const ConvArgs& a);

@@ -193,31 +193,80 @@ View Yolov8::c2f(const WeightPack& p, const std::string& name, const View& x, in
     const int cout = (int)p.get(name + ".cv2.conv.weight").dims[0];
     const int c = cout / 2;
     if (c % 16) fail(RMR_ERR_RUNTIME, "C2f '%s': hidden width %d is not a multiple of 16", name.c_str(), c);
-    View cat = alloc(x.h, x.w, (2 + n) * c);
+    // Chunks as planar slabs where both 1x1 convs can run on conv_pw (the only kernel that addresses
+    // slabs) and a chunk is narrower than two cache lines: the 3x3 convs in between then stream
+    // contiguous rows (2-2.7x read amplification on 96-byte slices of 384-byte pixels)
+    const int cu = up ? up->c : 0, cin1 = up ? x.c : x.c;
+    const bool slab = slabs_ && (c == 48 || c == 96) && pw_can(cin1, 2 * c, x.h, x.w, up != nullptr) &&
+                      pw_can((2 + n) * c, cout, x.h, x.w, false) &&
+                      (double)chunk_ * x.h * x.w * c * 2.0 * (2 + n) < 3.9e9;  // 32-bit offsets across the slabs
+    std::vector<View> chunk(2 + n);
+    View cat{};
+    if (slab) {
+        for (int i = 0; i < 2 + n; ++i) {
+            chunk[i] = alloc(x.h, x.w, c);
+            if (i && chunk[i].off - chunk[i - 1].off != chunk[1].off - chunk[0].off)
+                fail(RMR_ERR_LOGIC, "planner: slabs are not equally spaced");
+        }
+    } else {
+        cat = alloc(x.h, x.w, (2 + n) * c);
+        for (int i = 0; i < 2 + n; ++i) chunk[i] = slice(cat, i * c, c);
+    }
+    const size_t step = slab ? chunk[1].off - chunk[0].off : 0;
+    View cv1_out = slab ? chunk[0] : slice(cat, 0, 2 * c);
+    cv1_out.c = 2 * c;
     if (up) {
         // cv1 over concat[up2x(U), S] = SiLU(W_S.S + b + up2x(W_U.U)): the U half at a quarter of the
         // pixels, in f32, added by the S half's epilogue (ConvArgs::pre)
-        const int cu = up->c, cs = x.c;
+        const int cs = x.c;
         View t = alloc(up->h, up->w, 2 * c, true);
         conv(add_conv_weights(p, name + ".cv1.conv", 0, 0, cu, true), *up, t, 1, 0, nullptr, true);
-        conv(add_conv_weights(p, name + ".cv1.conv", 0, cu, cs), x, slice(cat, 0, 2 * c), 1, 1, nullptr, false, false, &t);
+        conv(add_conv_weights(p, name + ".cv1.conv", 0, cu, cs), x, cv1_out, 1, 1, nullptr, false, false, &t);
         // the model's own count for this layer: 2 * K * N at full resolution (the two launches
         // above declared what they execute, 3/4 of the U half less)
         flops_ += 2.0 * x.h * x.w * (double)(2 * c) * cu * 0.75;
     } else {
-        conv(add_conv_weights(p, name + ".cv1.conv", 0), x, slice(cat, 0, 2 * c), 1, 1);
+        conv(add_conv_weights(p, name + ".cv1.conv", 0), x, cv1_out, 1, 1);
+    }
+    if (slab) {
+        ops_.back().out_slab_c = c;
+        ops_.back().out_slab_step = step;
     }
     for (int i = 0; i < n; ++i) {
         View tmp = alloc(x.h, x.w, c);
-        const View prev = slice(cat, (1 + i) * c, c);
+        const View prev = chunk[1 + i];
         const std::string m = name + ".m." + std::to_string(i);
         conv(add_conv_weights(p, m + ".cv1.conv", 0), prev, tmp, 1, 1);
-        conv(add_conv_weights(p, m + ".cv2.conv", 0), tmp, slice(cat, (2 + i) * c, c), 1, 1,
-             shortcut ? &prev : nullptr);
+        conv(add_conv_weights(p, m + ".cv2.conv", 0), tmp, chunk[2 + i], 1, 1, shortcut ? &prev : nullptr);
     }
     View out = out_view ? *out_view : alloc(x.h, x.w, cout);
-    conv(add_conv_weights(p, name + ".cv2.conv", 0), cat, out, 1, 1);
+    View cv2_in = slab ? chunk[0] : cat;
+    cv2_in.c = (2 + n) * c;
+    conv(add_conv_weights(p, name + ".cv2.conv", 0), cv2_in, out, 1, 1);
+    if (slab) {
+        ops_.back().in_slab_c = c;
+        ops_.back().in_slab_step = step;
+    }
     return out;
+}
+
+// whether conv_pw has a variant for a 1x1 layer of this shape (the planner's slab decision)
+bool Yolov8::pw_can(int K, int N, int h, int w, bool pre) const {
+    ConvArgs a{};
+    a.KH = a.KW = 1;
+    a.stride = 1;
+    a.H = a.Ho = h;
+    a.W = a.Wo = w;
+    a.Cin = a.K = a.Kp = K;
+    a.Cout_pad = N;
+    a.in_cs = K;
+    a.out_cs = N;
+    a.N = 1;
+    a.M = h * w;
+    a.in_bytes = 1;
+    a.out = (__half*)1;
+    if (pre) a.pre = (const float*)1;
+    return conv_pw_supported(a, -1);
 }
 
 static int make_divisible(double x, int d) { return (int)std::ceil(x / d) * d; }
@@ -240,6 +289,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     if (const char* e = std::getenv("RMR_GRAPH")) graph_max_batch_ = atoi(e);
     if (const char* e = std::getenv("RMR_FUSE_LB")) fuse_lb_ = atoi(e) != 0;
     if (const char* e = std::getenv("RMR_FUSE_UP")) fuse_up_ = atoi(e) != 0;
+    if (const char* e = std::getenv("RMR_SLABS")) slabs_ = atoi(e) != 0;
     chunk_ = std::min(chunk, max_batch);
 
     int ch[5];
@@ -360,6 +410,8 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
 // (layer, batch) -- the analogue of the reference's TensorRT engine build (detector.cpp:177-243).
 void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     const int split = choice / 1000, c = choice % 1000;
+    if ((a.in_slab_c || a.out_slab_c) && (c < 700 || split))
+        fail(RMR_ERR_LOGIC, "kernel %d cannot address planar channel groups", choice);
     if (c >= 700) {
         launch_conv_pw(ctx_, s, a, c - 700);
     } else if (c >= 600) {
@@ -389,16 +441,17 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     // one that samples the frames directly: the same arithmetic whichever way the input arrives
     if (conv_stem_supported(a)) return 500;
     std::vector<int> cands;
-    for (int t = 0; t < conv_num_tiles(); ++t)
+    const bool slabbed = a.in_slab_c || a.out_slab_c;  // only conv_pw addresses planar channel groups
+    for (int t = 0; t < conv_num_tiles() && !slabbed; ++t)
         if (a.Cout_pad % conv_tile(t).bn == 0) cands.push_back(t);
-    if (conv_dma_supported(a))
+    if (!slabbed && conv_dma_supported(a))
         for (int t = 0; t < conv_dma_num_tiles(); ++t)
             if (a.Cout_pad % conv_dma_tile(t).bn == 0) cands.push_back(100 + t);
     if (!a.pre && conv_halo_supported(a, -1))
         for (int t = 0; t < conv_halo_num_tiles(); ++t)
             if (conv_halo_supported(a, t)) cands.push_back(200 + t);
     // fragment-direct tiles only where the staged kernels cannot fill the chip
-    if (conv_direct_supported(a, -1) && a.M <= 64 * ctx_.num_cus)
+    if (!slabbed && conv_direct_supported(a, -1) && a.M <= 64 * ctx_.num_cus)
         for (int t = 0; t < conv_direct_num_tiles(); ++t)
             if (conv_direct_supported(a, t)) cands.push_back(400 + t);
     if (conv_pw_supported(a, -1))
@@ -411,7 +464,7 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
         for (int v = 0; v < conv_ws_num_variants(); ++v)
             if (conv_ws_supported(a, v)) cands.push_back(300 + v);
     // split-K variants where the plain grid cannot fill the chip (small batches)
-    if (conv_dma_supported(a))
+    if (!slabbed && conv_dma_supported(a))
         for (int t = 0; t < conv_dma_num_tiles(); ++t) {
             const ConvTile ct = conv_dma_tile(t);
             if (a.Cout_pad % ct.bn || ct.bm * ct.bn > 128 * 128) continue;
@@ -480,7 +533,7 @@ unsigned long long Yolov8::plan_signature() const {
     unsigned long long h = 1469598103934665603ull;
     const auto mix = [&](long long v) { h = (h ^ (unsigned long long)v) * 1099511628211ull; };
     for (const Op& op : ops_) {
-        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c);
+        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs);
         if (op.kind == OP_CONV) mix(convs_[op.conv].K), mix(convs_[op.conv].cout_pad);
     }
     return h;
@@ -553,12 +606,21 @@ ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
         a.pre = fptr(op.pre);
         a.pre_cs = op.pre.cs;
     }
+    if (op.in_slab_c) {
+        a.in_slab_c = op.in_slab_c;
+        a.in_slab_stride = (unsigned)(op.in_slab_step * chunk_ * sizeof(__half));
+    }
+    if (op.out_slab_c) {
+        a.out_slab_c = op.out_slab_c;
+        a.out_slab_stride = (unsigned)(op.out_slab_step * chunk_ * sizeof(__half));
+    }
     a.Cout_pad = cw.cout_pad;
     a.K = cw.K;
     a.Kp = cw.Kp;
     a.M = n * a.Ho * a.Wo;
     a.act = op.act;
-    a.in_bytes = (unsigned)((size_t)n * a.H * a.W * a.in_cs * sizeof(__half));
+    a.in_bytes = (unsigned)((size_t)n * a.H * a.W * a.in_cs * sizeof(__half) +
+                            (op.in_slab_c ? (size_t)(op.in.c / op.in_slab_c - 1) * op.in_slab_step * chunk_ * sizeof(__half) : 0));
     a.wt_bytes = (unsigned)((size_t)cw.cout_pad * cw.Kp * sizeof(__half));
     a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
     return a;
@@ -576,7 +638,13 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
                 break;
             }
             if (!autotune_) {
-                launch_conv_auto(ctx_, s, a);
+                if (a.in_slab_c || a.out_slab_c) {
+                    int v = 0;
+                    while (!conv_pw_supported(a, v)) ++v;  // the planner checked that one exists
+                    launch_conv_pw(ctx_, s, a, v);
+                } else {
+                    launch_conv_auto(ctx_, s, a);
+                }
                 break;
             }
             auto key = std::make_pair(op_index, n);

@@ -302,3 +302,14 @@ def test_network_on_the_pointwise_kernels(rmr, packs, refs, images, oracle, monk
         _check_head(got[i:i + 1], want[i % 3:i % 3 + 1], 2.0, 1e-2)
     tuned = [l.split() for l in open(pack + ".tune").read().splitlines()[1:]]
     assert sum(1 for t in tuned if 700 <= int(t[2]) < 800) >= 10
+
+
+def test_interleaved_chunks_plan_still_matches(rmr, packs, refs, images, oracle, monkeypatch):
+    """RMR_SLABS=0: every C2f keeps its chunks as channel slices of one wide buffer (the layout before
+    conv_pw could address planar channel groups); the fallback for shapes conv_pw does not cover."""
+    monkeypatch.setenv("RMR_SLABS", "0")
+    det = rmr.Detector(packs[1], 12, (2592, 2048), 3, conf_thresh=0.5)
+    got, _ = det.infer(images)
+    det.close()
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    _check_head(got, refs["armor"][1].forward(blobs), 2.0, 1e-2)
