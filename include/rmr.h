@@ -140,7 +140,11 @@ rmr_status rmr_transpose(int device, const float* src, float* dst, int rows, int
 
 /* One conv+bias(+SiLU)(+residual) layer through the MFMA implicit-GEMM engine.
  * Host f32 in/out (converted to the engine's f16 NHWC internally): x [n][h][w][cin],
- * w [cout][cin][kh][kw] (OIHW), bias [cout], residual/y [n][ho][wo][cout]. tile<0 = auto. */
+ * w [cout][cin][kh][kw] (OIHW), bias [cout], residual/y [n][ho][wo][cout]. tile<0 = auto;
+ * otherwise the kernel to test: 0..99 conv_igemm tile, 100..199 conv_dma tile (+ 1000 * split for
+ * split-K), 200..299 conv_halo tile, 300..399 conv_ws variant, 400..499 conv_direct tile, 500 conv_stem,
+ * 600..699 conv_ws_s2 variant, 700..799 conv_pw variant; RMR_ERR_INVALID_ARGUMENT if it cannot run
+ * the layer. */
 rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, const float* wt,
                       const float* bias, int cout, int kh, int kw, int stride, int pad, int silu,
                       const float* residual, float* y, int tile);

@@ -31,7 +31,7 @@ fetch_kb, n_f, cols = per_launch(sys.argv[1], "FETCH_SIZE")
 write_kb, n_w, _ = per_launch(sys.argv[2], "WRITE_SIZE")
 out = {
     "round": 1,
-    "kernel": "conv_* (all instantiations of conv_igemm / conv_dma / conv_halo / conv_ws / conv_direct)",
+    "kernel": "conv_* (all instantiations of conv_igemm / conv_dma / conv_halo / conv_ws / conv_ws_s2 / conv_pw / conv_stem / conv_direct)",
     "command": sys.argv[4] if len(sys.argv) > 4 else "",
     "launches_counted": n_f,
     "FETCH_SIZE_kb_per_launch": fetch_kb,
