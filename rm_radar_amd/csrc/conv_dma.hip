@@ -107,7 +107,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dma_kernel(const ConvArgs a)
                            sgpr(a.in_bytes), sgpr(0x00020000u)};
     const u32x4 wt_rsrc = {sgpr((unsigned)(size_t)a.wt), sgpr((unsigned)((size_t)a.wt >> 32) & 0xffffu),
                            sgpr(a.wt_bytes), sgpr(0x00020000u)};
-    constexpr unsigned OOB = 0xfffffff0u;
 
     // ---- what this lane fetches: instruction slot j of this wave covers rows RPD*(wave + NW*j) ..
     const int lrow = lane / CPR;  // row within the DMA block

@@ -36,7 +36,6 @@ constexpr int S2_PLANE = 81 * S2_PIX;    // 81 pixels per parity plane
 constexpr int S2_SLOT = 16384;           // 2 planes (15552 B) padded to 16 DMA KiB
 constexpr int S2_SLOTS = 9;
 constexpr int S2_KSTEPS = 14;            // ceil(9 * 48 / 32)
-constexpr int S2_ROW_DMA = 16;           // DMA instructions per ring row
 constexpr int S2_LDS = S2_SLOTS * S2_SLOT;
 
 __device__ __forceinline__ float silu_2(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
