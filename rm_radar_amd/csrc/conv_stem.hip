@@ -233,12 +233,22 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, const 
         }
     }
     if (a.out32) return;
-    __syncthreads();
-    for (int ch = tid; ch < ST_TH * ST_TW * 6; ch += 256) {
-        const int p = ch / 6, part = ch - p * 6;
-        const int r = p / ST_TW, c = p - r * ST_TW;
-        const long m = ((long)img * a.Ho + oy0 + r) * a.Wo + ox0 + c;
-        *(u32x4*)((unsigned char*)a.out + (m * a.out_cs + a.out_co) * 2 + part * 16) = *(const u32x4*)(stage + ch * 16);
+    // each wave staged its own two rows (LDS operations of a wave execute in order: no barrier); a tile
+    // row is 192 chunks of 16 bytes, three per lane, at offsets that do not depend on the row
+    asm volatile("" ::: "memory");
+    unsigned coff[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int chunk = q * 64 + lane, c = chunk / 6, part = chunk - c * 6;
+        coff[q] = (unsigned)((c * a.out_cs + a.out_co) * 2 + part * 16);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * wave + rr;
+        unsigned char* const rowp = (unsigned char*)a.out + (((long)img * a.Ho + oy0 + r) * a.Wo + ox0) * a.out_cs * 2;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            *(u32x4*)(rowp + coff[q]) = *(const u32x4*)(stage + (r * ST_TW * 6 + q * 64 + lane) * 16);
     }
 }
 
