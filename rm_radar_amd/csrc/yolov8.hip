@@ -13,6 +13,7 @@
 #include "yolov8.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstdlib>
 #include <fstream>
 
@@ -495,6 +496,7 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     ctx_.prof.on = 0;
     int best = cands.front();
     float best_ms = 1e30f;
+    std::vector<std::pair<float, int>> timed;
     static const bool verbose = std::getenv("RMR_TUNE_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "tune M%d N%d K%d k%d s%d:", a.M, a.Cout_pad, a.K, a.KH, a.stride);
     for (int c : cands) {
@@ -517,6 +519,30 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
         }
         if (verbose) fprintf(stderr, " %d:%.1f", c, ms_min * 1e3f);
         if (ms_min < best_ms) best_ms = ms_min, best = c;
+        timed.emplace_back(ms_min, c);
+    }
+    // run-off: single launches a few percent apart are within the noise of one measurement (and of the
+    // box: sessions differed by 3 % in their picks); the finalists run five times back to back, which is
+    // also how they will run inside the network
+    std::sort(timed.begin(), timed.end());
+    size_t finalists = 0;
+    while (finalists < timed.size() && finalists < 4 && timed[finalists].first <= 1.04f * best_ms) ++finalists;
+    if (finalists > 1) {
+        best_ms = 1e30f;
+        for (size_t f = 0; f < finalists; ++f) {
+            float ms_min = 1e30f;
+            for (int rep = 0; rep < 2; ++rep) {
+                RMR_HIP(hipEventRecord(e0, s));
+                for (int k = 0; k < 5; ++k) launch_choice(s, a, timed[f].second);
+                RMR_HIP(hipEventRecord(e1, s));
+                RMR_HIP(hipEventSynchronize(e1));
+                float ms = 0;
+                RMR_HIP(hipEventElapsedTime(&ms, e0, e1));
+                ms_min = std::min(ms_min, ms / 5);
+            }
+            if (verbose) fprintf(stderr, " [%d:%.1f]", timed[f].second, ms_min * 1e3f);
+            if (ms_min < best_ms) best_ms = ms_min, best = timed[f].second;
+        }
     }
     if (verbose) fprintf(stderr, "  -> %d (%.1f us)\n", best, best_ms * 1e3f);
     ctx_.prof.on = prof_was_on;
