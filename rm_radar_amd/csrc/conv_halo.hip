@@ -348,6 +348,10 @@ const HaloTile kHaloTiles[] = {
     HTILE_T(8, 2, 2, 9, 4, 1),   // 30: 256 x 288
     HTILE_T(8, 2, 4, 3, 6, 1),   // 31: 512 x 96
     HTILE_T(8, 2, 4, 3, 16, 3),  // 32: 512 x 96, one barrier per filter row
+    // 320 rows: at 256 images per launch the 40x40 maps give 1280 row blocks, exactly five rounds over
+    // 256 CUs, where 256-row tiles leave a quarter-full last round (281 vs 295 us on the 192-channel
+    // layers without a shortcut; the 320 x 96 sibling needs 138 VGPRs, i.e. one workgroup per CU: slower)
+    HTILE(4, 2, 5, 6),           // 33: 320 x 192
 };
 constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
 
