@@ -238,21 +238,35 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
             const unsigned char* bp = smem + b_frag + stage_off + (t % TPS) * B_TAP_BYTES;
             half8 xf[MREP], wf[NREP];
 #pragma unroll
-            for (int i = 0; i < MREP; ++i) {
-                // a tap outside the image reads the zero block instead: ONE select on the address
-                // before the read, not four on the data between the read and the MFMA
+            for (int j = 0; j < NREP; ++j) wf[j] = *(const half8*)(bp + j * 16 * 64);
+            // a tap outside the image reads the zero block instead: ONE select on the address
+            // before the read, not four on the data between the read and the MFMA
+            const auto read_x = [&](int i) {
                 const int row = a_row[i] + shift;
                 const int at = a_buf + row * 64 + ((kg ^ hkey(row)) * 16);
                 const bool ok = (a_mask[i] >> t) & 1u;
-                xf[i] = *(const half8*)(smem + (ok ? at : zero_off));
+                return *(const half8*)(smem + (ok ? at : zero_off));
+            };
+            if (MREP > 4) {
+                // tall tiles: fragments two at a time, so that five of them are never live at once
+                xf[0] = read_x(0);
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) {
+                    if (i + 1 < MREP) xf[i + 1] = read_x(i + 1);
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) xf[i] = read_x(i);
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < NREP; ++j) wf[j] = *(const half8*)(bp + j * 16 * 64);
-#pragma unroll
-            for (int i = 0; i < MREP; ++i)
-#pragma unroll
-                for (int j = 0; j < NREP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
           }
         }
     }
@@ -348,10 +362,13 @@ const HaloTile kHaloTiles[] = {
     HTILE_T(8, 2, 2, 9, 4, 1),   // 30: 256 x 288
     HTILE_T(8, 2, 4, 3, 6, 1),   // 31: 512 x 96
     HTILE_T(8, 2, 4, 3, 16, 3),  // 32: 512 x 96, one barrier per filter row
-    // 320 rows: at 256 images per launch the 40x40 maps give 1280 row blocks, exactly five rounds over
-    // 256 CUs, where 256-row tiles leave a quarter-full last round (281 vs 295 us on the 192-channel
-    // layers without a shortcut; the 320 x 96 sibling needs 138 VGPRs, i.e. one workgroup per CU: slower)
+    // 320 rows: at 256 images per launch the 40x40 maps give 1280 row blocks x 2 channel tiles = exactly
+    // five rounds over 256 CUs x 2 workgroups, where 256-row tiles leave a quarter-full last round: 303 vs
+    // 326 us on the 192-channel layers with a shortcut, 281 vs 293 without.  (Fragments are read two at a
+    // time in these tiles: with all five live the 320 x 96 tile needs 138 VGPRs and loses its second
+    // workgroup per CU.  On 80-wide maps its input range does not leave LDS room for two either.)
     HTILE(4, 2, 5, 6),           // 33: 320 x 192
+    HTILE(4, 2, 5, 3),           // 34: 320 x 96
 };
 constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
 

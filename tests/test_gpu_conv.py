@@ -119,7 +119,7 @@ def test_conv_halo_every_tile(rmr):
              # whole-chunk slices (9 taps per barrier), then one filter row per barrier
              (64, 48), (128, 48), (256, 48), (64, 96), (128, 96), (64, 32), (128, 32), (64, 64), (128, 64), (32, 96),
              (128, 192), (256, 192), (256, 96), (256, 192), (256, 96), (256, 288), (512, 96), (512, 96),
-             (320, 192)]
+             (320, 192), (320, 96)]
     for t, (bm, bn) in enumerate(tiles):
         run_case(rmr, 3, 20, 20, 64, bn, 3, 1, True, True, tile=200 + t, seed=t)          # 3 images per ~5 tiles
         run_case(rmr, 1, 19, 23, 32, bn * 2, 3, 1, True, False, tile=200 + t, seed=40 + t)  # odd W, ragged M
