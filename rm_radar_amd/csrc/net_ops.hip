@@ -17,37 +17,40 @@ __device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
 // and the three chained 5x5 max-pools run as separable row / column passes on it (max is
 // separable and -inf padding just shrinks the window), so x is read once and every pass works
 // out of LDS.  Replaces a 13 x 13 brute-force sweep per pixel (57 us -> a few us at batch 1).
-constexpr int SPPF_MAX_PX = 1600;  // up to 40 x 40 per slab
+constexpr int SPPF_LDS_HALF8 = 3200;  // half8 slots: 2 buffers x pixels x channel groups per workgroup
 
+// G consecutive 8-channel groups per workgroup: G adjacent threads read G x 16 contiguous bytes of a pixel
 __global__ __launch_bounds__(256) void sppf_pools_kernel(__half* __restrict__ buf, int N, int H,
-                                                         int W, int cs, int co, int C) {
-    __shared__ __attribute__((aligned(16))) half8 cur[SPPF_MAX_PX], tmp[SPPF_MAX_PX];
-    const int cg = C / 8;
-    const int n = blockIdx.x / cg, g = blockIdx.x % cg;
-    const int npx = H * W;
-    _Float16* base = (_Float16*)buf + ((long)n * npx) * cs + co + g * 8;
-    for (int p = threadIdx.x; p < npx; p += 256) cur[p] = *(const half8*)(base + (long)p * cs);
+                                                         int W, int cs, int co, int C, int G) {
+    __shared__ __attribute__((aligned(16))) half8 lds[SPPF_LDS_HALF8];
+    const int npx = H * W, cnt = npx * G;
+    half8* const cur = lds;
+    half8* const tmp = lds + cnt;
+    const int wg_per_img = C / (8 * G);
+    const int n = blockIdx.x / wg_per_img, g0 = (blockIdx.x % wg_per_img) * G;
+    _Float16* base = (_Float16*)buf + ((long)n * npx) * cs + co + g0 * 8;
+    for (int i = threadIdx.x; i < cnt; i += 256) cur[i] = *(const half8*)(base + (long)(i / G) * cs + (i % G) * 8);
     __syncthreads();
     for (int level = 1; level <= 3; ++level) {
-        for (int p = threadIdx.x; p < npx; p += 256) {  // row pass
-            const int y = p / W, x = p % W;
-            half8 m = cur[p];
+        for (int i = threadIdx.x; i < cnt; i += 256) {  // row pass
+            const int p = i / G, q = i - p * G, y = p / W, x = p - y * W;
+            half8 m = cur[i];
             for (int d = -2; d <= 2; ++d) {
                 const int xx = x + d;
-                if (d != 0 && xx >= 0 && xx < W) m = hmax8(m, cur[y * W + xx]);
+                if (d != 0 && xx >= 0 && xx < W) m = hmax8(m, cur[(y * W + xx) * G + q]);
             }
-            tmp[p] = m;
+            tmp[i] = m;
         }
         __syncthreads();
-        for (int p = threadIdx.x; p < npx; p += 256) {  // column pass
-            const int y = p / W, x = p % W;
-            half8 m = tmp[p];
+        for (int i = threadIdx.x; i < cnt; i += 256) {  // column pass
+            const int p = i / G, q = i - p * G, y = p / W, x = p - y * W;
+            half8 m = tmp[i];
             for (int d = -2; d <= 2; ++d) {
                 const int yy = y + d;
-                if (d != 0 && yy >= 0 && yy < H) m = hmax8(m, tmp[yy * W + x]);
+                if (d != 0 && yy >= 0 && yy < H) m = hmax8(m, tmp[(yy * W + x) * G + q]);
             }
-            cur[p] = m;
-            *(half8*)(base + (long)p * cs + level * C) = m;
+            cur[i] = m;
+            *(half8*)(base + (long)p * cs + level * C + q * 8) = m;
         }
         __syncthreads();
     }
@@ -55,10 +58,15 @@ __global__ __launch_bounds__(256) void sppf_pools_kernel(__half* __restrict__ bu
 
 void launch_sppf_pools(DeviceCtx& ctx, hipStream_t s, __half* buf, int N, int H, int W, int cs,
                        int co, int C) {
-    if (H * W > SPPF_MAX_PX) fail(RMR_ERR_LOGIC, "sppf: %dx%d feature map exceeds the LDS slab", H, W);
+    if (2 * H * W > SPPF_LDS_HALF8) fail(RMR_ERR_LOGIC, "sppf: %dx%d feature map exceeds the LDS slab", H, W);
+    // as many channel groups per workgroup as LDS holds (4 at 20 x 20: 64-byte reads), dividing C / 8
+    // -- as long as the grid still covers the chip twice (small batches keep one group per workgroup)
+    int G = 1;
+    for (int g = 2; g <= 8; ++g)
+        if ((C / 8) % g == 0 && 2 * H * W * g <= SPPF_LDS_HALF8 && (long)N * (C / 8 / g) >= 2L * ctx.num_cus) G = g;
     const long total = (long)N * H * W * (C / 8);
     ProfScope ps(ctx.prof, s, "sppf_pools", 0, (double)total * 16 * 4);
-    sppf_pools_kernel<<<N * (C / 8), 256, 0, s>>>(buf, N, H, W, cs, co, C);
+    sppf_pools_kernel<<<N * (C / 8 / G), 256, 0, s>>>(buf, N, H, W, cs, co, C, G);
     RMR_HIP(hipGetLastError());
 }
 
