@@ -247,7 +247,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
                 const bool ok = (a_mask[i] >> t) & 1u;
                 return *(const half8*)(smem + (ok ? at : zero_off));
             };
-            if (MREP > 4) {
+            if (MREP > 4 && NREP <= 3) {
                 // tall tiles: fragments two at a time, so that five of them are never live at once (the same
                 // order costs the 256 x 128 tile 14 %, although it would take it from 129 to 117 VGPRs)
                 xf[0] = read_x(0);
