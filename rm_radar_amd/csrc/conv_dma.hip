@@ -443,6 +443,10 @@ const DmaTile kDmaTiles[] = {
     DTILE(4, 1, 1, 2, 6, 64),  // 41:  64 x 32, BK 64
     DTILE(2, 2, 1, 2, 8, 32),  // 42:  32 x 64
     DTILE(2, 2, 1, 3, 8, 32),  // 43:  32 x 96
+    // 320 rows: whole rounds at 256 images (1280 row blocks on the 40 x 40 maps), as in conv_halo
+    DTILE(4, 2, 5, 6, 3, 32),  // 44: 320 x 192
+    DTILE(4, 2, 5, 6, 2, 64),  // 45: 320 x 192, BK 64
+    DTILE(4, 2, 5, 4, 3, 32),  // 46: 320 x 128
 };
 constexpr int kNumDmaTiles = sizeof(kDmaTiles) / sizeof(kDmaTiles[0]);
 

@@ -95,6 +95,10 @@ def test_conv_dma_every_tile(rmr):
     run_case(rmr, 1, 9, 9, 64, 96, 5, 1, True, False, tile=102, seed=8)                 # 5x5 window
     run_case(rmr, 2, 20, 20, 96, 96, 3, 1, True, True, tile=122, seed=9)                # BK 64, Cin 96: slices straddle taps
     run_case(rmr, 1, 20, 20, 288, 288, 3, 1, True, True, tile=132, seed=10)             # K = 2592 = 40.5 slices of 64
+    for t, bn in ((144, 192), (145, 192), (146, 128)):                                   # 320-row tiles
+        run_case(rmr, 1, 19, 23, 64, bn * 2, 3, 1, True, True, tile=t, seed=t)
+        run_case(rmr, 2, 40, 40, 96, bn, 3, 2, True, False, tile=t, seed=t + 1)          # stride 2, 800 rows
+        run_case(rmr, 2, 16, 16, 96, bn, 1, 1, False, False, tile=t, seed=t + 2)
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 4, 4, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
                    False, tile=100)  # Cin = 48 is not a multiple of 32
