@@ -27,6 +27,7 @@
 //
 // Staged bytes per K slice at 256 x 192: 16 KiB instead of 28 KiB (im2col), and the A part no
 // longer grows with the tile height.
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -111,7 +112,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     // ---- DMA bookkeeping of this lane -------------------------------------------------------
     const int lrow = lane >> 2;                       // row inside a 16-row DMA block
     const int lchunk = (lane & 3) ^ hkey(lrow);       // logical 16-byte chunk this lane fetches
-    const int na = a_rows / 16;                       // input-range DMA instructions per chunk
+    // a_rows is a multiple of 8 (>= 16); the last 16-row DMA block starts at a_rows - 16, overlapping its
+    // predecessor by eight rows when a_rows is not a multiple of 16 (same data, same swizzle phase) instead
+    // of running past the buffer
+    const int na = (a_rows + 15) / 16;                // input-range DMA instructions per chunk
+    const auto a_blk = [&](int ia) { return min(ia * 16, a_rows - 16); };  // first row of block ia
     // weight rows of this lane's B slots (slot q = wave + NW*j; q >= A_SLOTS are weights: instruction
     // wi = q - A_SLOTS covers rows 16 (wi % NB) .. +15 of tap wi / NB of the slice)
     int w_off[NI];
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
     const int ch_in_chunk = lchunk * 8;
 
     const unsigned scratch = sgpr(lds0 + b_base + BSTAGES * B_STAGE_BYTES);  // idle slots land here
-    const int zero_off = b_base + BSTAGES * B_STAGE_BYTES + 1024;            // 16 zero bytes: what padding taps read
+    const int zero_off = b_base + BSTAGES * B_STAGE_BYTES;                   // 16 zero bytes: what padding taps read --
+    // the head of the scratch KiB: idle slots are out-of-range loads, which write zeros, so it stays zero
     if (tid == 0) *(u32x4*)(smem + zero_off) = u32x4{0, 0, 0, 0};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave reaches the first barrier
 
@@ -147,12 +153,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
             const int q = wave + NW * j;  // wave-uniform slot
             if (q < A_SLOTS) {
                 const int ia = g * A_SLOTS + q;     // DMA block within the input range
-                const int p = lo + ia * 16 + lrow;  // input pixel of this lane's row
+                const int r0 = a_blk(ia);
+                const int p = lo + r0 + lrow;  // input pixel of this lane's row
                 if (a_live && ia < na) {
                     unsigned off = OOB;
                     if (p >= 0 && p < npix && (cc + 1) * 32 + ch_in_chunk < a.Cin)
                         off = (unsigned)((p * a.in_cs + a.in_co + (cc + 1) * 32 + lchunk * 8) * 2);
-                    dma16h(in_rsrc, sgpr(lds0 + ((cc + 1) & 1) * a_buf_bytes + ia * 1024), off);
+                    dma16h(in_rsrc, sgpr(lds0 + ((cc + 1) & 1) * a_buf_bytes + r0 * 64), off);
                 } else if (BSTAGES > 2) {
                     dma16h(in_rsrc, scratch, OOB);  // keeps the counted vmcnt immediates constant
                 }
@@ -174,10 +181,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const ConvArgs a
 
     // ---- prologue: the whole input range of chunk 0, weight slices 0 .. BSTAGES-2 ------------
     for (int ia = wave; ia < na; ia += NW) {
-        const int p = lo + ia * 16 + lrow;
+        const int r0 = a_blk(ia);
+        const int p = lo + r0 + lrow;
         unsigned off = OOB;
         if (p >= 0 && p < npix && ch_in_chunk < a.Cin) off = (unsigned)((p * a.in_cs + a.in_co + lchunk * 8) * 2);
-        dma16h(in_rsrc, sgpr(lds0 + ia * 1024), off);
+        dma16h(in_rsrc, sgpr(lds0 + r0 * 64), off);
     }
     // weight slices 0 .. BSTAGES-2
 #pragma unroll
@@ -373,10 +381,10 @@ const HaloTile kHaloTiles[] = {
 };
 constexpr int kNumHaloTiles = sizeof(kHaloTiles) / sizeof(kHaloTiles[0]);
 
-int halo_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
+int halo_rows(int bm, int W) { return std::max(16, (bm + 2 * W + 2 + 7) / 8 * 8); }
 int halo_lds_bytes(const HaloTile& t, int W) {
     const int stages = t.tps == 9 ? 2 : 3;
-    return 2 * halo_rows(t.bm, W) * 64 + stages * t.bn * 64 * t.tps + 1024 + 64;  // + one scratch KiB for idle slots, + the zero block
+    return 2 * halo_rows(t.bm, W) * 64 + stages * t.bn * 64 * t.tps + 1024;  // + one scratch KiB for idle slots (its head is the zero block)
 }
 
 }  // namespace
