@@ -143,11 +143,18 @@ rmr_status rmr_transpose(int device, const float* src, float* dst, int rows, int
  * w [cout][cin][kh][kw] (OIHW), bias [cout], residual/y [n][ho][wo][cout]. tile<0 = auto;
  * otherwise the kernel to test: 0..99 conv_igemm tile, 100..199 conv_dma tile (+ 1000 * split for
  * split-K), 200..299 conv_halo tile, 300..399 conv_ws variant, 400..499 conv_direct tile, 500 conv_stem,
- * 600..699 conv_ws_s2 variant, 700..799 conv_pw variant; RMR_ERR_INVALID_ARGUMENT if it cannot run
- * the layer. */
+ * 600..699 conv_ws_s2 variant, 700..799 conv_pw variant, 800..899 conv_t32 tile;
+ * RMR_ERR_INVALID_ARGUMENT if it cannot run the layer. */
 rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, const float* wt,
                       const float* bias, int cout, int kh, int kw, int stride, int pad, int silu,
                       const float* residual, float* y, int tile);
+
+/* Development hook: times one conv layer (bias + SiLU, f16 in / f16 out, optional residual) on
+ * device-resident pseudo-random data with HIP events; kernel = a tiled family id as in rmr_conv2d
+ * (0..299, 800..899).  *ms_out = mean launch time over `reps` launches.  No reference counterpart
+ * (TensorRT's builder times its tactics the same way, detector.cpp:208-231). */
+rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, int k, int stride,
+                          int residual, int kernel, int reps, float* ms_out);
 
 /* ---------------------------------------------------------------- Detector */
 

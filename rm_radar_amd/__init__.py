@@ -155,6 +155,14 @@ def conv2d(x_nhwc, w_oihw, bias, stride, pad, silu, residual=None, tile=-1, devi
     return y
 
 
+def conv_bench(n, h, w, cin, cout, k, stride, kernel, residual=False, reps=10, device=0):
+    """Mean launch time in ms of one conv layer (f16 in / out, bias + SiLU) on device-resident random data
+    with the tiled kernel `kernel` (ids as conv2d's `tile`).  Development hook behind tools/conv_bench.py."""
+    ms = C.c_float(0.0)
+    check(lib().rmr_conv_bench(device, n, h, w, cin, cout, k, stride, int(bool(residual)), kernel, reps, C.byref(ms)))
+    return ms.value
+
+
 # ------------------------------------------------------------------------------- Robot
 
 @dataclass

@@ -130,6 +130,7 @@ SYMBOLS = {
     "rmr_transpose": (C.c_int, [C.c_int, _fp, _fp, C.c_int, C.c_int]),
     "rmr_conv2d": (C.c_int, [C.c_int, _fp] + [C.c_int] * 4 + [_fp, _fp] + [C.c_int] * 6 +
                    [_fp, _fp, C.c_int]),
+    "rmr_conv_bench": (C.c_int, [C.c_int] * 11 + [_fp]),
     "rmr_detector_cfg_default": (None, [_P(DetectorCfg)]),
     "rmr_detector_create": (C.c_int, [_P(DetectorCfg), _P(_vp)]),
     "rmr_detector_destroy": (None, [_vp]),

@@ -1,5 +1,6 @@
 // api_detect.cpp -- C-ABI entry points (include/rmr.h) for Detector, RobotDetector and the
 // single-layer conv hook.
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -159,6 +160,16 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         a.act = silu;
         a.in_bytes = (unsigned)(hx.size() * sizeof(__half));
         a.wt_bytes = (unsigned)(packed.size() * sizeof(__half));
+        DevBuf<__half> dw32;
+        if (kh == 3 && kw == 3 && cin_pad % 32 == 0) {
+            std::vector<__half> p32;
+            pack_conv_weights_t32(packed.data(), cout_pad, cin_pad, a.Kp, p32);
+            dw32.alloc(p32.size());
+            RMR_HIP(hipMemcpyAsync(dw32.p, p32.data(), p32.size() * sizeof(__half), hipMemcpyHostToDevice, ctx.stream));
+            RMR_HIP(hipStreamSynchronize(ctx.stream));  // p32 dies at the end of this block
+            a.wt_t32 = dw32.p;
+            a.wt_t32_bytes = (unsigned)(p32.size() * sizeof(__half));
+        }
         DevBuf<long long> dtiming;
         // per-phase cycle stamps of conv_dma / conv_direct: needs a build with -DRMR_CONV_TIMING_BUILD=1
         const bool want_timing = std::getenv("RMR_CONV_TIMING") != nullptr;
@@ -167,9 +178,14 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             RMR_HIP(hipMemsetAsync(dtiming.p, 0, 64, ctx.stream));
             a.timing = dtiming.p;
         }
-        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..: conv_pw variant
+        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..799: conv_pw variant; 800..899: conv_t32 tile
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
+        } else if (tile >= 800 && tile < 900) {
+            const int t = tile - 800;
+            if (t >= conv_t32_num_tiles() || !conv_t32_supported(a, t))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: t32 tile %d cannot run this layer", t);
+            launch_conv_t32(ctx, ctx.stream, a, t);
         } else if (tile >= 1000) {
             // 1000 * split + 100 + dma tile: split-K through a private workspace
             const int split = tile / 1000, t = tile % 1000 - 100;
@@ -232,6 +248,125 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         }
         for (size_t p = 0; p < npx_out; ++p)
             for (int c = 0; c < cout; ++c) y[p * cout + c] = hy[p * cout_pad + c];
+    });
+}
+
+// One layer on device-resident f16 data, timed with HIP events: the kernel-development loop (tools/conv_bench.py).
+// x: random f16 NHWC (one image's worth replicated), f16 output, optional residual; `tile` as in rmr_conv2d
+// (only the tiled families: 0..299, 800..899).  ms_out = mean launch time over `reps` launches.
+rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, int k, int stride, int residual, int tile,
+                          int reps, float* ms_out) {
+    return guarded([&] {
+        if (!ms_out || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 8 || cout <= 0 || cout % 16 || reps <= 0)
+            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: bad arguments");
+        DeviceCtx& ctx = device_ctx(device);
+        const int pad = k / 2;
+        const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+        const size_t img_in = (size_t)h * w * cin, img_out = (size_t)ho * wo * cout;
+        if ((double)n * img_in * 2 > 3.7e9) fail(RMR_ERR_CAPACITY, "rmr_conv_bench: input view larger than 3.7 GB");
+        std::vector<__half> hx(img_in), hw;
+        unsigned seed = 12345u;
+        const auto rnd = [&] {
+            seed = seed * 1664525u + 1013904223u;
+            return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f;
+        };
+        // RMR_BENCH_DATA: 0 = uniform [-1, 1) (default), 1 = zeros, 2 = SiLU-like (what the layers of the
+        // network see: SiLU of a unit normal-ish value, mostly small, never below -0.28)
+        const int mode = std::getenv("RMR_BENCH_DATA") ? std::atoi(std::getenv("RMR_BENCH_DATA")) : 0;
+        for (auto& v : hx) {
+            float x = rnd();
+            if (mode == 1) x = 0.f;
+            if (mode == 2) {
+                const float g = (rnd() + rnd() + x) * 1.0f;  // roughly normal, sigma ~ 1
+                x = g / (1.0f + std::exp(-g));
+            }
+            v = __float2half(x);
+        }
+        std::vector<float> wf((size_t)cout * cin * k * k), b(cout);
+        const float ws = 1.0f / std::sqrt((float)cin * k * k);
+        for (auto& v : wf) v = rnd() * ws;
+        for (auto& v : b) v = rnd() * 0.5f;
+        ConvArgs a{};
+        pack_conv_weights(wf.data(), cout, cin, k, k, cin, cout, hw, a.K, a.Kp);
+        DevBuf<__half> dx, dw, dw32, dy, dr;
+        DevBuf<float> db;
+        dx.alloc(n * img_in);
+        dw.alloc(hw.size());
+        db.alloc(b.size());
+        dy.alloc(n * img_out);
+        RMR_HIP(hipMemcpy(dx.p, hx.data(), img_in * 2, hipMemcpyHostToDevice));
+        for (int i = 1; i < n; ++i) RMR_HIP(hipMemcpyAsync(dx.p + i * img_in, dx.p, img_in * 2, hipMemcpyDeviceToDevice, ctx.stream));
+        RMR_HIP(hipMemcpy(dw.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+        RMR_HIP(hipMemcpy(db.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        if (residual) {
+            dr.alloc(n * img_out);
+            RMR_HIP(hipMemcpyAsync(dr.p, dx.p, std::min(n * img_out, n * img_in) * 2, hipMemcpyDeviceToDevice, ctx.stream));
+            a.res = dr.p;
+            a.res_cs = cout;
+        }
+        if (k == 3 && cin % 32 == 0) {
+            std::vector<__half> p32;
+            pack_conv_weights_t32(hw.data(), cout, cin, a.Kp, p32);
+            dw32.alloc(p32.size());
+            RMR_HIP(hipMemcpy(dw32.p, p32.data(), p32.size() * 2, hipMemcpyHostToDevice));
+            a.wt_t32 = dw32.p;
+            a.wt_t32_bytes = (unsigned)(p32.size() * 2);
+        }
+        a.in = dx.p;
+        a.in_cs = cin;
+        a.N = n;
+        a.H = h;
+        a.W = w;
+        a.Cin = cin;
+        a.Ho = ho;
+        a.Wo = wo;
+        a.KH = a.KW = k;
+        a.stride = stride;
+        a.pad = pad;
+        a.wt = dw.p;
+        a.bias = db.p;
+        a.out = dy.p;
+        a.out_cs = cout;
+        a.Cout_pad = cout;
+        a.M = n * ho * wo;
+        a.act = 1;
+        a.in_bytes = (unsigned)(n * img_in * 2);
+        a.wt_bytes = (unsigned)(hw.size() * 2);
+        const auto launch = [&] {
+            if (tile >= 800 && tile < 900) {
+                if (tile - 800 >= conv_t32_num_tiles() || !conv_t32_supported(a, tile - 800))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: t32 tile %d cannot run this layer", tile - 800);
+                launch_conv_t32(ctx, ctx.stream, a, tile - 800);
+            } else if (tile >= 200 && tile < 300) {
+                if (tile - 200 >= conv_halo_num_tiles() || !conv_halo_supported(a, tile - 200))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: halo tile %d cannot run this layer", tile - 200);
+                launch_conv_halo(ctx, ctx.stream, a, tile - 200);
+            } else if (tile >= 100 && tile < 200) {
+                if (tile - 100 >= conv_dma_num_tiles() || cout % conv_dma_tile(tile - 100).bn || !conv_dma_supported(a))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: dma tile %d cannot run this layer", tile - 100);
+                launch_conv_dma(ctx, ctx.stream, a, tile - 100);
+            } else if (tile >= 0 && tile < 100) {
+                if (tile >= conv_num_tiles() || cout % conv_tile(tile).bn)
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: tile %d cannot run this layer", tile);
+                launch_conv(ctx, ctx.stream, a, tile);
+            } else {
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: kernel id %d is not a tiled family", tile);
+            }
+        };
+        launch();
+        launch();
+        hipEvent_t e0, e1;
+        RMR_HIP(hipEventCreate(&e0));
+        RMR_HIP(hipEventCreate(&e1));
+        RMR_HIP(hipEventRecord(e0, ctx.stream));
+        for (int r = 0; r < reps; ++r) launch();
+        RMR_HIP(hipEventRecord(e1, ctx.stream));
+        RMR_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        RMR_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_out = ms / reps;
     });
 }
 

@@ -38,6 +38,9 @@ struct ConvArgs {
     int act;            // 1 = SiLU
     unsigned in_bytes;  // bytes addressable from `in` (buffer-load bounds: reads past it return 0)
     unsigned wt_bytes;  // bytes of the packed weights
+    // conv_t32 only: the same weights as the LDS images of their (chunk, tap) slices (pack_conv_weights_t32)
+    const __half* wt_t32;
+    unsigned wt_t32_bytes;
     // split-K (conv_dma only): `split` workgroups share one output tile, each accumulating a
     // contiguous range of K slices; partial tiles meet in splitk_ws and the last arriver (ticket in
     // splitk_cnt, which it resets to 0) reduces them and runs the epilogue.  split <= 1: off.
@@ -103,6 +106,13 @@ void launch_conv_stem_letterbox(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, 
 int conv_ws_s2_num_variants();
 bool conv_ws_s2_supported(const ConvArgs& a, int variant);  // variant < 0: any
 void launch_conv_ws_s2(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant);
+// 3x3 / stride-1 layers with Cin % 32 == 0 on 32x32x16 MFMAs (conv_t32.hip): one 8-wave workgroup per
+// CU, fragment reads half a tap ahead of the MFMAs, weights pre-packed as LDS images (a.wt_t32)
+int conv_t32_num_tiles();
+ConvTile conv_t32_tile(int id);
+bool conv_t32_supported(const ConvArgs& a, int tile);  // tile < 0: any
+void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+void pack_conv_weights_t32(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out);
 // picks the kernel family and tile for a layer (RMR_CONV=igemm|dma overrides) and launches it
 void launch_conv_auto(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a);
 

@@ -1,0 +1,502 @@
+// conv_t32.hip -- 3x3 / stride 1 / pad 1 convolution on v_mfma_f32_32x32x16_f16, one 8-wave
+// workgroup per CU, written so that the K loop carries almost no scalar or vector-ALU work.
+//
+// conv_halo (round 1) stages the input range once per 32-channel chunk and takes the nine taps as
+// row shifts of the fragment reads; measured, its K loop is not short of bytes but of issue slots
+// and overlap: 7.6 VALU + 2.7 SALU per 16x16x32 MFMA, one barrier per 12-24 MFMAs with the fragment
+// reads AFTER it, 45 % of the wave time parked.  This kernel keeps the halo staging and changes
+// everything around it:
+//
+//   * 32x32x16 MFMAs (half the matrix instructions per FLOP, 32-cycle issue slots to hide the rest
+//     in), a wave tile of 64 pixels x 96..128 channels, 8 waves = 256 x 192 or 512 x 96 per CU so that
+//     the weight stream is shared by 256-512 pixels (one workgroup per CU, up to 256 VGPRs);
+//   * weights are re-packed on the host into the exact LDS image of a (chunk, tap) slice, swizzle
+//     included, so a weight DMA instruction reads ONE contiguous KiB (eight whole 128-byte lines)
+//     from a wave-uniform offset: lane * 16 in the VGPR, everything else in the scalar offset;
+//   * fragment reads run half a tap ahead of the MFMAs that consume them, ACROSS the barrier: a
+//     slice is waited for (counted vmcnt) one tap before its first read, so the reads of tap t + 1
+//     are legal before the barrier that opens tap t + 1, and the MFMAs behind a barrier start at once;
+//   * border taps are masked by redirecting the fragment read to a zero block, as before, but the
+//     nine validity bits of a lane live in SGPR pairs as lane masks (one v_cndmask per fragment and
+//     tap), and fragment i of a wave sits at a constant 2 KiB from fragment 0 (immediate offsets):
+//     the swizzle key has a period of 16 rows, so ONE address is computed per tap.
+//
+// LDS rows are 64 bytes (32 channels of one pixel / one output channel).  A lane of a 32x32x16
+// fragment read (row = lane & 31, k-half = lane >> 5) takes the 16-byte chunk (2 h + k-half) of its
+// row for the MFMA of K-step h; chunk c of row r is stored at slot c ^ ((r >> 2) & 3), which makes
+// every ds_read_b128 lane group cover all 64 banks once at every row shift.
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <type_traits>
+
+#include "conv_igemm.h"
+
+namespace rmr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float silu_t(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// LDS-DMA: 64 lanes x 16 bytes land at lds_addr + lane * 16; source = rsrc base + voff + soff
+__device__ __forceinline__ void dma16s(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+template <int T>
+using tap_c = std::integral_constant<int, T>;
+
+// f(integral_constant<0>) ... f(integral_constant<N-1>): a loop whose index is a constant expression
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (K < N) {
+        f(std::integral_constant<int, K>{});
+        static_for<K + 1, N>(f);
+    }
+}
+
+// WM x WN waves, MREP x NREP fragments of 32 x 32 per wave, A_SLOTS input-range DMA instructions per
+// tap (the first 11 - R taps of a chunk carry the next chunk's range), R weight slices in the ring
+template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int ABL = 0>
+__global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a, const int a_rows) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * MREP * 32;
+    constexpr int BN = WN * NREP * 32;
+    constexpr int NB = BN / 16;                 // weight DMA instructions per tap
+    constexpr int SLOTS = NB + A_SLOTS;         // DMA instructions per tap (workgroup)
+    constexpr int D = (SLOTS + NW - 1) / NW;    // per wave
+    constexpr int SLOT_BYTES = BN * 64;         // one (chunk, tap) weight slice
+    constexpr int ATAPS = 11 - R;               // taps that carry input-range blocks
+    constexpr unsigned OOB = 0xffff0000u;
+    static_assert(R >= 4 && R <= 6, "ring depth");
+    static_assert((R - 3) * D <= 63, "vmcnt is 6 bits");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    const unsigned lds0 = sgpr((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const int a_buf_bytes = a_rows * 64;
+    const int ring_base = 2 * a_buf_bytes;
+    const int zero_off = ring_base + R * SLOT_BYTES;   // 64 zero bytes, head of the scratch KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nt_count = a.Cout_pad / BN;
+    const int nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int xcd = blockIdx.x & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int m0 = (lid / nt_count) * BM;
+    const int n0 = (lid % nt_count) * BN;
+    const int W = a.W;
+    const int lo = m0 - W - 1;   // input pixel held by LDS row 0
+    const int npix = a.M;        // stride 1: input and output pixels share the linear index
+
+    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
+                           sgpr(a.in_bytes), sgpr(0x00020000u)};
+    const u32x4 wt_rsrc = {sgpr((unsigned)(size_t)a.wt_t32), sgpr((unsigned)((size_t)a.wt_t32 >> 32) & 0xffffu),
+                           sgpr(a.wt_t32_bytes), sgpr(0x00020000u)};
+
+    // ---- DMA constants of this lane ----------------------------------------------------------
+    const int lrow = lane >> 2;                                   // row inside a 16-row DMA block
+    const int lch = (lane & 3) ^ ((lrow >> 2) & 3);               // logical 16-byte chunk it fetches
+    const int pl = lo + lrow;
+    const unsigned cs2 = (unsigned)a.in_cs * 2u;
+    const unsigned in_cb = (unsigned)((a.in_co + lch * 8) * 2);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int na = a_rows / 16;                                   // input-range DMA blocks per chunk
+    const int chunks = a.Cin / 32;
+    const int total = chunks * 9;
+    const unsigned wstep = (unsigned)(a.Cout_pad / 16) * 1024u;   // bytes of one (chunk, tap) slice of all channels
+    const unsigned scratch = sgpr(lds0 + zero_off);
+
+    if (tid < 4) *(u32x4*)(smem + zero_off + tid * 16) = u32x4{0, 0, 0, 0};
+
+    const auto in_off = [&](int ia, int cc) {  // byte offset of this lane's piece of input block ia, chunk cc
+        const int p = min(max(pl + ia * 16, 0), npix - 1);  // out-of-range pixels are only ever read by masked taps
+        return __umul24((unsigned)p, cs2) + in_cb + (unsigned)cc * 64u;
+    };
+
+    // DMA slot j of this wave is q = wave + NW * j: a weight block (q < NB) or an input-range block, for the
+    // whole kernel -- the role is chosen once, the issue code in the K loop has no branches
+    bool s_isw[D];
+    u32x4 s_rsrc[D];
+    unsigned s_wdst[D], s_wsrc[D];
+    int s_aidx[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const int q = wave + NW * j;
+        s_isw[j] = q < NB;
+        s_rsrc[j] = NW * (j + 1) <= NB ? wt_rsrc : NW * j >= NB ? in_rsrc : (s_isw[j] ? wt_rsrc : in_rsrc);
+        s_wdst[j] = lds0 + ring_base + q * 1024;
+        s_wsrc[j] = (unsigned)(n0 / 16 + q) * 1024u;
+        s_aidx[j] = q - NB;
+    }
+
+    // ---- prologue: the whole input range of chunk 0, weight slices 0 .. R-2 ----------------------
+    for (int ia = wave; ia < na; ia += NW) dma16s(in_rsrc, sgpr(lds0 + ia * 1024), in_off(ia, 0), 0u);
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s)
+        for (int q = wave; q < NB; q += NW)
+            dma16s(wt_rsrc, sgpr(lds0 + ring_base + s * SLOT_BYTES + q * 1024), s < total ? lane16 : OOB,
+                   sgpr((unsigned)s * wstep + (unsigned)(n0 / 16 + q) * 1024u));
+
+    // ---- fragment constants ------------------------------------------------------------------------
+    const int fr = lane & 31, kq = lane >> 5;
+    const int a_row0 = wm * MREP * 32 + fr + W + 1;   // LDS row of the centre tap of fragment 0
+    // valid taps of this lane's pixel, as four lane masks per fragment (rows past M compute garbage
+    // that is never stored: an MFMA column is one pixel)
+    bool up[MREP], dn[MREP], lf[MREP], rt[MREP];
+    int zsel[MREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + (wm * MREP + i) * 32 + fr;
+        const int x = m % W, y = (m / W) % a.H;
+        up[i] = y > 0;
+        dn[i] = y < a.H - 1;
+        lf[i] = x > 0;
+        rt[i] = x < W - 1;
+        zsel[i] = zero_off - i * 2048;
+    }
+    const int wlane = ring_base + (wn * NREP * 32 + fr) * 64 + ((kq ^ ((fr >> 2) & 3)) << 4);
+
+    floatx16 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const auto lds16 = [&](int off) { return *(const half8*)(smem + off); };
+    // address of fragment 0's chunk for K-step 0 of tap t, in input buffer `abuf`
+    const auto a_addr = [&](int abuf, int t) {
+        const int row = a_row0 + (t / 3 - 1) * W + (t % 3 - 1);
+        return abuf + row * 64 + ((kq ^ ((row >> 2) & 3)) << 4);
+    };
+
+    wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragments of (tap 0, K-step 0)
+    half8 xa[MREP], wa[NREP], xb[MREP], wb[NREP];
+    int selx[MREP];
+    int wcur = wlane;
+    if constexpr (ABL == 5 || ABL >= 7) {
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) xb[i] = lds16(a_addr(0, 4) + i * 2048);
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) wb[j] = lds16((wlane ^ 32) + j * 2048);
+    }
+    {
+        const int at = a_addr(0, 0);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            selx[i] = (up[i] && lf[i]) ? at : zsel[i];
+            xa[i] = lds16(selx[i] + i * 2048);
+        }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
+    }
+
+    constexpr int NM = MREP * NREP;   // MFMAs per K-step
+    int slot = 0;                     // ring slot of the tap being computed
+    unsigned gwoff = (unsigned)(R - 1) * wstep;   // byte offset of weight slice g + R - 1
+    int gw = R - 1;
+    for (int cc = 0; cc < chunks; ++cc) {
+        const int abuf = (cc & 1) * a_buf_bytes, abuf_next = a_buf_bytes - abuf;
+        const bool a_live = cc + 1 < chunks;
+        // One tap = 2 NM MFMAs (K-step 0, then K-step 1); everything else is placed by hand into the gaps
+        // behind them (a 32x32x16 MFMA occupies the pipe for 32 cycles).  The fragments of a K-step are read
+        // one K-step ahead: those of the next tap's K-step 0 BEFORE the barrier that opens that tap, so the
+        // first MFMAs behind a barrier never wait for the LDS.
+        const auto tap = [&](auto T) {
+            constexpr int t = decltype(T)::value;
+            constexpr int tn = (t + 1) % 9;
+            const int slot_w = slot == 0 ? R - 1 : slot - 1;
+            const unsigned wv = gw < total ? lane16 : OOB;
+            int at_n = 0;
+            if constexpr (ABL != 4 && ABL < 5) __builtin_amdgcn_s_barrier();
+            // fillers of K-step 0: the K-step 1 fragments of this tap (pixels, then weights), D DMA slots, the
+            // next tap's addresses; filler f rides behind MFMA f * NM / (D + 3)
+            const auto filler0 = [&](auto Fc) {
+                constexpr int f = decltype(Fc)::value;
+                if constexpr (f == 0) {
+                    if constexpr (ABL < 5 || ABL == 6) {
+#pragma unroll
+                        for (int i = 0; i < MREP; ++i) xb[i] = lds16((selx[i] ^ 32) + i * 2048);
+                    }
+                } else if constexpr (f == 1) {
+                    if constexpr (ABL < 5 || ABL == 6) {
+#pragma unroll
+                        for (int j = 0; j < NREP; ++j) wb[j] = lds16((wcur ^ 32) + j * 2048);
+                    }
+                } else if constexpr (f < 2 + D && (ABL == 3 || ABL >= 5)) {
+                } else if constexpr (f < 2 + D) {
+                    // ---- DMA slot d: weight slice g + R - 1 into the ring slot tap g - 1 left, or one block
+                    // of the next chunk's input range
+                    constexpr int d = f - 2;
+                    constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
+                    constexpr bool a_tap = t < ATAPS;
+                    const unsigned w_lds = s_wdst[d] + slot_w * SLOT_BYTES, w_soff = s_wsrc[d] + gwoff;
+                    const int ia = t * A_SLOTS + s_aidx[d];
+                    const bool alive = a_tap && a_live && ia < na;
+                    const unsigned a_lds = alive ? lds0 + abuf_next + ia * 1024 : scratch;
+                    if constexpr (all_w) {
+                        dma16s(wt_rsrc, sgpr(w_lds), wv, sgpr(w_soff));
+                    } else if constexpr (all_a) {
+                        if constexpr (a_tap) dma16s(in_rsrc, sgpr(a_lds), alive ? in_off(ia, cc + 1) : OOB, 0u);
+                    } else {
+                        const bool isw = s_isw[d];
+                        const unsigned av = (a_tap && alive) ? in_off(ia, cc + 1) : OOB;
+                        dma16s(s_rsrc[d], sgpr(isw ? w_lds : a_lds), isw ? wv : av, sgpr(isw ? w_soff : 0u));
+                    }
+                } else {
+                    at_n = a_addr(t == 8 ? abuf_next : abuf, tn);
+                    const int slot_n = slot + 1 == R ? 0 : slot + 1;
+                    wcur = wlane + slot_n * SLOT_BYTES;
+                    slot = slot_n;
+                }
+            };
+            static_for<0, NM>([&](auto Kc) {
+                constexpr int k = decltype(Kc)::value;
+                if constexpr (ABL != 1)
+                    acc[k / NREP][k % NREP] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[k % NREP], xa[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wa[k % NREP]), "v"(xa[k / NREP]));
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, D + 3>([&](auto Fc) {
+                    if constexpr (decltype(Fc)::value * NM / (D + 3) == k) filler0(Fc);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            static_for<0, NM>([&](auto Kc) {
+                constexpr int k = decltype(Kc)::value;
+                if constexpr (ABL != 1)
+                    acc[k / NREP][k % NREP] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[k % NREP], xb[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
+                else
+                    asm volatile("" ::"v"(wb[k % NREP]), "v"(xb[k / NREP]));
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (k == 0) {
+                    // K-step 0 fragments of the next tap (tap 0 of the next chunk after tap 8): legal before the
+                    // next barrier because that slice was waited for one tap ago
+                    constexpr int dy = tn / 3 - 1, dx = tn % 3 - 1;
+#pragma unroll
+                    for (int i = 0; i < MREP; ++i) {
+                        const bool v = (dy < 0 ? up[i] : dy > 0 ? dn[i] : true) && (dx < 0 ? lf[i] : dx > 0 ? rt[i] : true);
+                        selx[i] = v ? at_n : zsel[i];
+                        if constexpr (ABL < 5 || ABL == 6) xa[i] = lds16(selx[i] + i * 2048);
+                    }
+                }
+                if constexpr (k == (NM > 1 ? 1 : 0) && (ABL < 5 || ABL == 6)) {
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // DMAs issued R - 3 taps ago (and earlier) have landed: slice g + 2 and the input blocks that rode with it
+            constexpr int pending = [] {
+                int n = 0;
+                for (int k = 0; k < R - 3; ++k) {
+                    const int tt = (t - k + 9) % 9;
+                    for (int j = 0; j < D; ++j) n += (NW * j >= NB && tt >= ATAPS) ? 0 : 1;
+                }
+                return n;
+            }();
+            if constexpr (ABL != 2 && ABL != 3 && ABL < 5) wait_vm<pending>();
+            gwoff += wstep;
+            ++gw;
+        };
+        tap(tap_c<0>{});
+        tap(tap_c<1>{});
+        tap(tap_c<2>{});
+        tap(tap_c<3>{});
+        tap(tap_c<4>{});
+        tap(tap_c<5>{});
+        tap(tap_c<6>{});
+        tap(tap_c<7>{});
+        tap(tap_c<8>{});
+    }
+    wait_vm<0>();
+
+    // ---- epilogue: bias, SiLU, residual; a lane holds 4 x 4 consecutive channels of one pixel per fragment
+    const int cq = kq * 4;
+    if constexpr (ABL == 9) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) a.out[0] = (__half)t;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + (wm * MREP + i) * 32 + fr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + (wn * NREP + j) * 32 + gq * 8 + cq;
+                const float4 b = *(const float4*)(a.bias + n);
+                float v[4] = {acc[i][j][gq * 4 + 0] + b.x, acc[i][j][gq * 4 + 1] + b.y, acc[i][j][gq * 4 + 2] + b.z,
+                              acc[i][j][gq * 4 + 3] + b.w};
+                if (a.act && ABL != 8) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = silu_t(v[r]);
+                }
+                if constexpr (ABL == 7) {
+                    if (v[0] + v[1] + v[2] + v[3] != 12345.678f) continue;
+                }
+                if (a.res) {
+                    union {
+                        uint2 u;
+                        _Float16 h[4];
+                    } rr;
+                    rr.u = *(const uint2*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rr.h[r];
+                }
+                if (a.out32) {
+                    *(float4*)(a.out32 + (long)m * a.out_cs + a.out_co + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    union {
+                        uint2 u;
+                        _Float16 h[4];
+                    } o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.h[r] = (_Float16)v[r];
+                    *(uint2*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + n) = o.u;
+                }
+            }
+        }
+    }
+}
+
+struct T32Tile {
+    int bm, bn, threads, a_slots, ring;
+    void (*kernel)(const ConvArgs, int);
+};
+
+#define T32(WM, WN, MR, NR, AS, R) \
+    { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, conv_t32_kernel<WM, WN, MR, NR, AS, R> }
+#define T32A(WM, WN, MR, NR, AS, R, ABL) \
+    { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, conv_t32_kernel<WM, WN, MR, NR, AS, R, ABL> }
+
+const T32Tile kT32Tiles[] = {
+    T32(4, 2, 2, 3, 4, 5),    // 0: 256 x 192, 40-wide maps (22 input blocks over 6 taps), one workgroup per CU
+    T32(4, 2, 2, 3, 4, 4),    // 1: 256 x 192, up to 80-wide maps (27 blocks over 7 taps)
+    T32(8, 1, 2, 3, 10, 5),   // 2: 512 x 96
+    T32(4, 2, 2, 4, 8, 4),    // 3: 256 x 256 (fused head convs)
+    T32(8, 1, 2, 2, 12, 5),   // 4: 512 x 64
+    T32(4, 2, 1, 3, 4, 5),    // 5: 128 x 192
+    T32(8, 1, 1, 3, 10, 5),   // 6: 256 x 96
+    // two workgroups per CU (<= 128 VGPRs, <= 80 KiB of LDS): one's epilogue under the other's K loop
+    T32(8, 1, 1, 3, 10, 4),   // 7: 256 x 96
+    T32(8, 1, 1, 2, 12, 4),   // 8: 256 x 64
+    T32(8, 1, 1, 4, 8, 4),    // 9: 256 x 128
+    T32(4, 2, 1, 3, 4, 4),    // 10: 128 x 192
+    T32A(4, 2, 2, 3, 4, 5, 1),  // 11: ablation: no MFMA
+    T32A(8, 1, 1, 3, 10, 4, 1),  // 12: ablation of 7: no MFMA
+    T32A(8, 1, 1, 3, 10, 4, 3),  // 13: no DMA
+    T32A(8, 1, 1, 3, 10, 4, 4),  // 14: no barrier
+    T32A(4, 2, 2, 3, 4, 5, 5),  // 15: MFMA only
+    T32A(4, 2, 2, 3, 4, 5, 6),  // 16: MFMA + LDS reads
+    T32A(8, 1, 1, 3, 10, 4, 5),  // 17: MFMA only (2 WG/CU)
+    T32A(8, 1, 1, 3, 10, 4, 6),  // 18: MFMA + LDS reads (2 WG/CU)
+    T32A(4, 2, 2, 3, 4, 5, 7),  // 19: MFMA only, no stores
+    T32A(4, 2, 2, 3, 4, 5, 8),  // 20: MFMA only, no SiLU
+    T32A(4, 2, 2, 3, 4, 5, 9),  // 21: MFMA only, no epilogue
+};
+constexpr int kNumT32Tiles = sizeof(kT32Tiles) / sizeof(kT32Tiles[0]);
+
+int t32_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
+int t32_lds_bytes(const T32Tile& t, int W) { return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024; }
+
+}  // namespace
+
+int conv_t32_num_tiles() { return kNumT32Tiles; }
+ConvTile conv_t32_tile(int id) { return ConvTile{kT32Tiles[id].bm, kT32Tiles[id].bn, 32}; }
+
+bool conv_t32_supported(const ConvArgs& a, int tile) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 32 || a.Cin < 32) return false;
+    if (a.Ho != a.H || a.Wo != a.W || a.pre || a.in_slab_c || a.out_slab_c || !a.wt_t32) return false;
+    if (tile < 0) return true;
+    const T32Tile& t = kT32Tiles[tile];
+    const int na = t32_rows(t.bm, a.W) / 16;
+    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && t32_lds_bytes(t, a.W) <= 160 * 1024;
+}
+
+void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
+    if (tile < 0 || tile >= kNumT32Tiles) fail(RMR_ERR_INVALID_ARGUMENT, "conv_t32: tile %d out of range", tile);
+    if (!conv_t32_supported(a, tile)) fail(RMR_ERR_LOGIC, "conv_t32: layer not supported by tile %d", tile);
+    const T32Tile& t = kT32Tiles[tile];
+    if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4) fail(RMR_ERR_LOGIC, "conv_t32: misaligned view");
+    if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull || a.wt_t32_bytes == 0)
+        fail(RMR_ERR_LOGIC, "conv_t32: buffer sizes not set or input view larger than 3.75 GiB");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const T32Tile& d : kT32Tiles)
+            (void)hipFuncSetAttribute((const void*)d.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    const int rows = t32_rows(t.bm, a.W);
+    const int lds = t32_lds_bytes(t, a.W);
+    const int grid = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
+    const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
+    static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
+    static std::mutex name_mu;
+    static std::map<std::string, std::string> names;
+    const char* pname = "conv_igemm_f16";
+    if (per_layer && ctx.prof.on) {
+        char buf[48];
+        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d g%d", a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
+        std::lock_guard<std::mutex> lk(name_mu);
+        pname = names.emplace(buf, buf).first->second.c_str();
+    }
+    ProfScope ps(ctx.prof, stream, pname, flops, bytes);
+    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows);
+    RMR_HIP(hipGetLastError());
+}
+
+// [Cout_pad][Kp] (k = tap * Cin + ci) -> [chunk][tap][Cout_pad / 16][64 lanes][8]: the LDS image of every
+// (chunk, tap) slice in the order the DMA writes it (lane l: row l >> 2, slot l & 3 holds chunk slot ^ key(row))
+void pack_conv_weights_t32(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out) {
+    const int chunks = cin / 32, nblk = cout_pad / 16;
+    out.assign((size_t)chunks * 9 * nblk * 512, __float2half(0.f));
+    for (int cc = 0; cc < chunks; ++cc)
+        for (int t = 0; t < 9; ++t)
+            for (int b = 0; b < nblk; ++b)
+                for (int l = 0; l < 64; ++l) {
+                    const int r = l >> 2, s = l & 3;
+                    const int n = b * 16 + r;
+                    const int c = s ^ ((r >> 2) & 3);
+                    const __half* src = packed + (size_t)n * Kp + (size_t)t * cin + cc * 32 + c * 8;
+                    __half* dst = out.data() + ((((size_t)cc * 9 + t) * nblk + b) * 64 + l) * 8;
+                    for (int e = 0; e < 8; ++e) dst[e] = src[e];
+                }
+}
+
+}  // namespace rmr
