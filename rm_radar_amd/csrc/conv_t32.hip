@@ -70,9 +70,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // WM x WN waves, MREP x NREP fragments of 32 x 32 per wave, A_SLOTS input-range DMA instructions per
-// tap (the first 11 - R taps of a chunk carry the next chunk's range), R weight slices in the ring
-template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int ABL = 0>
-__global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a, const int a_rows) {
+// tap (the first 11 - R taps of a chunk carry the next chunk's range), R weight slices in the ring.
+// EPI: 0 = results leave through v_permlane32_swap pairs as 16-byte stores (32 contiguous bytes per pixel),
+//      1 = through a per-wave LDS stage as whole rows (NREP * 64 contiguous bytes per pixel).
+//
+// PERSISTENT: the grid is at most a few workgroups per CU and a workgroup walks tiles vb = b, b + G, ...
+// The DMA stream does not stop at a tile's end: the last R - 1 taps of a tile fetch the first weight
+// slices of the next one and its last chunk fetches the next tile's first input range, so only the very
+// first tile of a workgroup pays a cold start, and the epilogue of a tile runs while the next tile's
+// operands are already in flight.
+template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 32;
     constexpr int BN = WN * NREP * 32;
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     constexpr int D = (SLOTS + NW - 1) / NW;    // per wave
     constexpr int SLOT_BYTES = BN * 64;         // one (chunk, tap) weight slice
     constexpr int ATAPS = 11 - R;               // taps that carry input-range blocks
+    constexpr int STG_PITCH = NREP * 64 + 16;   // bytes per pixel row of the epilogue stage
     constexpr unsigned OOB = 0xffff0000u;
     static_assert(R >= 4 && R <= 6, "ring depth");
     static_assert((R - 3) * D <= 63, "vmcnt is 6 bits");
@@ -96,16 +105,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int stg_base = zero_off + 1024 + wave * 32 * STG_PITCH;
 
+    // tile vb -> (m0, n0); XCD-aware: the tiles of one XCD (vb & 7) are a contiguous range, n-tiles innermost
     const int nt_count = a.Cout_pad / BN;
-    const int nwg = gridDim.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int xcd = blockIdx.x & 7;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int m0 = (lid / nt_count) * BM;
-    const int n0 = (lid % nt_count) * BN;
+    const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
+    const int G = gridDim.x;  // a multiple of 8: vb & 7 is this workgroup's XCD for every tile it walks
+    const auto tile_m0n0 = [&](int vb, int& m0, int& n0) {
+        const int xcd = vb & 7;
+        const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+        m0 = (lid / nt_count) * BM;
+        n0 = (lid % nt_count) * BN;
+    };
+    int vb = blockIdx.x;
+    if (vb >= n_tiles) return;
+    int m0, n0;
+    tile_m0n0(vb, m0, n0);
     const int W = a.W;
-    const int lo = m0 - W - 1;   // input pixel held by LDS row 0
     const int npix = a.M;        // stride 1: input and output pixels share the linear index
 
     const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
@@ -116,7 +132,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     // ---- DMA constants of this lane ----------------------------------------------------------
     const int lrow = lane >> 2;                                   // row inside a 16-row DMA block
     const int lch = (lane & 3) ^ ((lrow >> 2) & 3);               // logical 16-byte chunk it fetches
-    const int pl = lo + lrow;
     const unsigned cs2 = (unsigned)a.in_cs * 2u;
     const unsigned in_cb = (unsigned)((a.in_co + lch * 8) * 2);
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -128,8 +143,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
 
     if (tid < 4) *(u32x4*)(smem + zero_off + tid * 16) = u32x4{0, 0, 0, 0};
 
-    const auto in_off = [&](int ia, int cc) {  // byte offset of this lane's piece of input block ia, chunk cc
-        const int p = min(max(pl + ia * 16, 0), npix - 1);  // out-of-range pixels are only ever read by masked taps
+    // byte offset of this lane's piece of input block ia of a tile whose LDS row 0 is pixel lo, channel chunk cc
+    const auto in_off = [&](int lo_l, int ia, int cc) {
+        const int p = min(max(lo_l + ia * 16, 0), npix - 1);  // out-of-range pixels are only ever read by masked taps
         return __umul24((unsigned)p, cs2) + in_cb + (unsigned)cc * 64u;
     };
 
@@ -145,45 +161,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
         s_isw[j] = q < NB;
         s_rsrc[j] = NW * (j + 1) <= NB ? wt_rsrc : NW * j >= NB ? in_rsrc : (s_isw[j] ? wt_rsrc : in_rsrc);
         s_wdst[j] = lds0 + ring_base + q * 1024;
-        s_wsrc[j] = (unsigned)(n0 / 16 + q) * 1024u;
+        s_wsrc[j] = (unsigned)q * 1024u;
         s_aidx[j] = q - NB;
     }
 
-    // ---- prologue: the whole input range of chunk 0, weight slices 0 .. R-2 ----------------------
-    for (int ia = wave; ia < na; ia += NW) dma16s(in_rsrc, sgpr(lds0 + ia * 1024), in_off(ia, 0), 0u);
+    // ---- cold start: the whole input range of chunk 0, weight slices 0 .. R-2 of the first tile -----------
+    {
+        const int pl0 = m0 - W - 1 + lrow;
+        for (int ia = wave; ia < na; ia += NW) dma16s(in_rsrc, sgpr(lds0 + ia * 1024), in_off(pl0, ia, 0), 0u);
 #pragma unroll
-    for (int s = 0; s < R - 1; ++s)
-        for (int q = wave; q < NB; q += NW)
-            dma16s(wt_rsrc, sgpr(lds0 + ring_base + s * SLOT_BYTES + q * 1024), s < total ? lane16 : OOB,
-                   sgpr((unsigned)s * wstep + (unsigned)(n0 / 16 + q) * 1024u));
+        for (int s = 0; s < R - 1; ++s)
+            for (int q = wave; q < NB; q += NW)
+                dma16s(wt_rsrc, sgpr(lds0 + ring_base + s * SLOT_BYTES + q * 1024), s < total ? lane16 : OOB,
+                       sgpr((unsigned)s * wstep + (unsigned)(n0 / 16 + q) * 1024u));
+    }
 
     // ---- fragment constants ------------------------------------------------------------------------
     const int fr = lane & 31, kq = lane >> 5;
     const int a_row0 = wm * MREP * 32 + fr + W + 1;   // LDS row of the centre tap of fragment 0
-    // valid taps of this lane's pixel, as four lane masks per fragment (rows past M compute garbage
-    // that is never stored: an MFMA column is one pixel)
-    bool up[MREP], dn[MREP], lf[MREP], rt[MREP];
     int zsel[MREP];
 #pragma unroll
-    for (int i = 0; i < MREP; ++i) {
-        const int m = m0 + (wm * MREP + i) * 32 + fr;
-        const int x = m % W, y = (m / W) % a.H;
-        up[i] = y > 0;
-        dn[i] = y < a.H - 1;
-        lf[i] = x > 0;
-        rt[i] = x < W - 1;
-        zsel[i] = zero_off - i * 2048;
-    }
+    for (int i = 0; i < MREP; ++i) zsel[i] = zero_off - i * 2048;
     const int wlane = ring_base + (wn * NREP * 32 + fr) * 64 + ((kq ^ ((fr >> 2) & 3)) << 4);
-
-    floatx16 acc[MREP][NREP];
-#pragma unroll
-    for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const auto lds16 = [&](int off) { return *(const half8*)(smem + off); };
     // address of fragment 0's chunk for K-step 0 of tap t, in input buffer `abuf`
     const auto a_addr = [&](int abuf, int t) {
@@ -195,245 +194,336 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // fragments of (tap 0, K-step 0)
-    half8 xa[MREP], wa[NREP], xb[MREP], wb[NREP];
-    int selx[MREP];
-    int wcur = wlane;
-    if constexpr (ABL == 5 || ABL >= 7) {
-#pragma unroll
-        for (int i = 0; i < MREP; ++i) xb[i] = lds16(a_addr(0, 4) + i * 2048);
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) wb[j] = lds16((wlane ^ 32) + j * 2048);
-    }
-    {
-        const int at = a_addr(0, 0);
-#pragma unroll
-        for (int i = 0; i < MREP; ++i) {
-            selx[i] = (up[i] && lf[i]) ? at : zsel[i];
-            xa[i] = lds16(selx[i] + i * 2048);
-        }
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
-    }
-
     constexpr int NM = MREP * NREP;   // MFMAs per K-step
     int slot = 0;                     // ring slot of the tap being computed
-    unsigned gwoff = (unsigned)(R - 1) * wstep;   // byte offset of weight slice g + R - 1
+    int abuf = 0;                     // input buffer of the chunk being computed
+    // the weight stream: slice gw of the tile whose channel-tile offset is w_tile is the next one to fetch
     int gw = R - 1;
-    for (int cc = 0; cc < chunks; ++cc) {
-        const int abuf = (cc & 1) * a_buf_bytes, abuf_next = a_buf_bytes - abuf;
-        const bool a_live = cc + 1 < chunks;
-        // One tap = 2 NM MFMAs (K-step 0, then K-step 1); everything else is placed by hand into the gaps
-        // behind them (a 32x32x16 MFMA occupies the pipe for 32 cycles).  The fragments of a K-step are read
-        // one K-step ahead: those of the next tap's K-step 0 BEFORE the barrier that opens that tap, so the
-        // first MFMAs behind a barrier never wait for the LDS.
-        const auto tap = [&](auto T) {
-            constexpr int t = decltype(T)::value;
-            constexpr int tn = (t + 1) % 9;
-            const int slot_w = slot == 0 ? R - 1 : slot - 1;
-            const unsigned wv = gw < total ? lane16 : OOB;
-            int at_n = 0;
-            if constexpr (ABL != 4 && ABL < 5) __builtin_amdgcn_s_barrier();
-            // fillers of K-step 0: the K-step 1 fragments of this tap (pixels, then weights), D DMA slots, the
-            // next tap's addresses; filler f rides behind MFMA f * NM / (D + 3)
-            const auto filler0 = [&](auto Fc) {
-                constexpr int f = decltype(Fc)::value;
-                if constexpr (f == 0) {
-                    if constexpr (ABL < 5 || ABL == 6) {
-#pragma unroll
-                        for (int i = 0; i < MREP; ++i) xb[i] = lds16((selx[i] ^ 32) + i * 2048);
-                    }
-                } else if constexpr (f == 1) {
-                    if constexpr (ABL < 5 || ABL == 6) {
-#pragma unroll
-                        for (int j = 0; j < NREP; ++j) wb[j] = lds16((wcur ^ 32) + j * 2048);
-                    }
-                } else if constexpr (f < 2 + D && (ABL == 3 || ABL >= 5)) {
-                } else if constexpr (f < 2 + D) {
-                    // ---- DMA slot d: weight slice g + R - 1 into the ring slot tap g - 1 left, or one block
-                    // of the next chunk's input range
-                    constexpr int d = f - 2;
-                    constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
-                    constexpr bool a_tap = t < ATAPS;
-                    const unsigned w_lds = s_wdst[d] + slot_w * SLOT_BYTES, w_soff = s_wsrc[d] + gwoff;
-                    const int ia = t * A_SLOTS + s_aidx[d];
-                    const bool alive = a_tap && a_live && ia < na;
-                    const unsigned a_lds = alive ? lds0 + abuf_next + ia * 1024 : scratch;
-                    if constexpr (all_w) {
-                        dma16s(wt_rsrc, sgpr(w_lds), wv, sgpr(w_soff));
-                    } else if constexpr (all_a) {
-                        if constexpr (a_tap) dma16s(in_rsrc, sgpr(a_lds), alive ? in_off(ia, cc + 1) : OOB, 0u);
-                    } else {
-                        const bool isw = s_isw[d];
-                        const unsigned av = (a_tap && alive) ? in_off(ia, cc + 1) : OOB;
-                        dma16s(s_rsrc[d], sgpr(isw ? w_lds : a_lds), isw ? wv : av, sgpr(isw ? w_soff : 0u));
-                    }
-                } else {
-                    at_n = a_addr(t == 8 ? abuf_next : abuf, tn);
-                    const int slot_n = slot + 1 == R ? 0 : slot + 1;
-                    wcur = wlane + slot_n * SLOT_BYTES;
-                    slot = slot_n;
-                }
-            };
-            static_for<0, NM>([&](auto Kc) {
-                constexpr int k = decltype(Kc)::value;
-                if constexpr (ABL != 1)
-                    acc[k / NREP][k % NREP] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[k % NREP], xa[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
-                else
-                    asm volatile("" ::"v"(wa[k % NREP]), "v"(xa[k / NREP]));
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<0, D + 3>([&](auto Fc) {
-                    if constexpr (decltype(Fc)::value * NM / (D + 3) == k) filler0(Fc);
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            static_for<0, NM>([&](auto Kc) {
-                constexpr int k = decltype(Kc)::value;
-                if constexpr (ABL != 1)
-                    acc[k / NREP][k % NREP] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[k % NREP], xb[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
-                else
-                    asm volatile("" ::"v"(wb[k % NREP]), "v"(xb[k / NREP]));
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (k == 0) {
-                    // K-step 0 fragments of the next tap (tap 0 of the next chunk after tap 8): legal before the
-                    // next barrier because that slice was waited for one tap ago
-                    constexpr int dy = tn / 3 - 1, dx = tn % 3 - 1;
-#pragma unroll
-                    for (int i = 0; i < MREP; ++i) {
-                        const bool v = (dy < 0 ? up[i] : dy > 0 ? dn[i] : true) && (dx < 0 ? lf[i] : dx > 0 ? rt[i] : true);
-                        selx[i] = v ? at_n : zsel[i];
-                        if constexpr (ABL < 5 || ABL == 6) xa[i] = lds16(selx[i] + i * 2048);
-                    }
-                }
-                if constexpr (k == (NM > 1 ? 1 : 0) && (ABL < 5 || ABL == 6)) {
-#pragma unroll
-                    for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            // DMAs issued R - 3 taps ago (and earlier) have landed: slice g + 2 and the input blocks that rode with it
-            constexpr int pending = [] {
-                int n = 0;
-                for (int k = 0; k < R - 3; ++k) {
-                    const int tt = (t - k + 9) % 9;
-                    for (int j = 0; j < D; ++j) n += (NW * j >= NB && tt >= ATAPS) ? 0 : 1;
-                }
-                return n;
-            }();
-            if constexpr (ABL != 2 && ABL != 3 && ABL < 5) wait_vm<pending>();
-            gwoff += wstep;
-            ++gw;
-        };
-        tap(tap_c<0>{});
-        tap(tap_c<1>{});
-        tap(tap_c<2>{});
-        tap(tap_c<3>{});
-        tap(tap_c<4>{});
-        tap(tap_c<5>{});
-        tap(tap_c<6>{});
-        tap(tap_c<7>{});
-        tap(tap_c<8>{});
-    }
-    wait_vm<0>();
+    unsigned gwoff = (unsigned)(R - 1) * wstep;
+    unsigned w_tile = (unsigned)(n0 / 16) * 1024u;
+    bool w_live = true;
 
-    // ---- epilogue: bias, SiLU, residual; a lane holds 4 x 4 consecutive channels of one pixel per fragment
-    const int cq = kq * 4;
-    if constexpr (ABL == 9) {
-        float t = 0.f;
+    for (;;) {
+        // ---- this tile and the next one -------------------------------------------------------------
+        const int vbn = vb + G;
+        const bool has_next = vbn < n_tiles;
+        int m0n = 0, n0n = 0;
+        if (has_next) tile_m0n0(vbn, m0n, n0n);
+        const int pl = m0 - W - 1 + lrow, pln = m0n - W - 1 + lrow;
+        // valid taps of this lane's pixel, as four lane masks per fragment (rows past M compute garbage
+        // that is never stored: an MFMA column is one pixel)
+        bool up[MREP], dn[MREP], lf[MREP], rt[MREP];
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            const int m = m0 + (wm * MREP + i) * 32 + fr;
+            const int x = m % W, y = (m / W) % a.H;
+            up[i] = y > 0;
+            dn[i] = y < a.H - 1;
+            lf[i] = x > 0;
+            rt[i] = x < W - 1;
+        }
+        floatx16 acc[MREP][NREP];
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
 #pragma unroll
             for (int j = 0; j < NREP; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-        if (t == 12345.678f) a.out[0] = (__half)t;
-        return;
-    }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // fragments of (tap 0, K-step 0): the slice and the range were waited for before the last barrier
+        half8 xa[MREP], wa[NREP], xb[MREP], wb[NREP];
+        int selx[MREP];
+        int wcur = wlane + slot * SLOT_BYTES;
+        {
+            const int at = a_addr(abuf, 0);
 #pragma unroll
-    for (int i = 0; i < MREP; ++i) {
-        const int m = m0 + (wm * MREP + i) * 32 + fr;
-        if (m >= a.M) continue;
+            for (int i = 0; i < MREP; ++i) {
+                selx[i] = (up[i] && lf[i]) ? at : zsel[i];
+                xa[i] = lds16(selx[i] + i * 2048);
+            }
 #pragma unroll
-        for (int j = 0; j < NREP; ++j) {
+            for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
+        }
+
+        for (int cc = 0; cc < chunks; ++cc) {
+            const int abuf_next = a_buf_bytes - abuf;
+            // the range fetched during this chunk: the next chunk of this tile, or chunk 0 of the next tile
+            const bool in_tile = cc + 1 < chunks;
+            const bool a_live = in_tile || has_next;
+            const int a_pl = in_tile ? pl : pln;
+            const int a_cc = in_tile ? cc + 1 : 0;
+            // One tap = 2 NM MFMAs (K-step 0, then K-step 1); everything else is placed by hand into the gaps
+            // behind them (a 32x32x16 MFMA occupies the pipe for 32 cycles).  The fragments of a K-step are read
+            // one K-step ahead: those of the next tap's K-step 0 BEFORE the barrier that opens that tap, so the
+            // first MFMAs behind a barrier never wait for the LDS.
+            const auto tap = [&](auto T) {
+                constexpr int t = decltype(T)::value;
+                constexpr int tn = (t + 1) % 9;
+                const int slot_w = slot == 0 ? R - 1 : slot - 1;
+                const unsigned wv = w_live ? lane16 : OOB;
+                int at_n = 0;
+                __builtin_amdgcn_s_barrier();
+                // fillers of K-step 0: the K-step 1 fragments of this tap (pixels, then weights), D DMA slots, the
+                // next tap's addresses; filler f rides behind MFMA f * NM / (D + 3)
+                const auto filler0 = [&](auto Fc) {
+                    constexpr int f = decltype(Fc)::value;
+                    if constexpr (f == 0) {
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n = n0 + (wn * NREP + j) * 32 + gq * 8 + cq;
-                const float4 b = *(const float4*)(a.bias + n);
-                float v[4] = {acc[i][j][gq * 4 + 0] + b.x, acc[i][j][gq * 4 + 1] + b.y, acc[i][j][gq * 4 + 2] + b.z,
-                              acc[i][j][gq * 4 + 3] + b.w};
-                if (a.act && ABL != 8) {
+                        for (int i = 0; i < MREP; ++i) xb[i] = lds16((selx[i] ^ 32) + i * 2048);
+                    } else if constexpr (f == 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = silu_t(v[r]);
+                        for (int j = 0; j < NREP; ++j) wb[j] = lds16((wcur ^ 32) + j * 2048);
+                    } else if constexpr (f < 2 + D) {
+                        // ---- DMA slot d: the next weight slice of the stream into the ring slot tap g - 1 left,
+                        // or one block of the next input range
+                        constexpr int d = f - 2;
+                        constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
+                        constexpr bool a_tap = t < ATAPS;
+                        const unsigned w_lds = s_wdst[d] + slot_w * SLOT_BYTES, w_soff = s_wsrc[d] + w_tile + gwoff;
+                        const int ia = t * A_SLOTS + s_aidx[d];
+                        const bool alive = a_tap && a_live && ia < na;
+                        const unsigned a_lds = alive ? lds0 + abuf_next + ia * 1024 : scratch;
+                        if constexpr (all_w) {
+                            dma16s(wt_rsrc, sgpr(w_lds), wv, sgpr(w_soff));
+                        } else if constexpr (all_a) {
+                            if constexpr (a_tap) dma16s(in_rsrc, sgpr(a_lds), alive ? in_off(a_pl, ia, a_cc) : OOB, 0u);
+                        } else {
+                            const bool isw = s_isw[d];
+                            const unsigned av = (a_tap && alive) ? in_off(a_pl, ia, a_cc) : OOB;
+                            dma16s(s_rsrc[d], sgpr(isw ? w_lds : a_lds), isw ? wv : av, sgpr(isw ? w_soff : 0u));
+                        }
+                    } else {
+                        at_n = a_addr(t == 8 ? abuf_next : abuf, tn);
+                        const int slot_n = slot + 1 == R ? 0 : slot + 1;
+                        wcur = wlane + slot_n * SLOT_BYTES;
+                        slot = slot_n;
+                    }
+                };
+                static_for<0, NM>([&](auto Kc) {
+                    constexpr int k = decltype(Kc)::value;
+                    acc[k / NREP][k % NREP] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[k % NREP], xa[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, D + 3>([&](auto Fc) {
+                        if constexpr (decltype(Fc)::value * NM / (D + 3) == k) filler0(Fc);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                static_for<0, NM>([&](auto Kc) {
+                    constexpr int k = decltype(Kc)::value;
+                    acc[k / NREP][k % NREP] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[k % NREP], xb[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (k == 0) {
+                        // K-step 0 fragments of the next tap (tap 0 of the next chunk after tap 8): legal before the
+                        // next barrier because that slice was waited for one tap ago.  (After the tile's last tap
+                        // they are read in vain: the next tile's lane masks are not known here.)
+                        constexpr int dy = tn / 3 - 1, dx = tn % 3 - 1;
+#pragma unroll
+                        for (int i = 0; i < MREP; ++i) {
+                            const bool v = (dy < 0 ? up[i] : dy > 0 ? dn[i] : true) && (dx < 0 ? lf[i] : dx > 0 ? rt[i] : true);
+                            selx[i] = v ? at_n : zsel[i];
+                            xa[i] = lds16(selx[i] + i * 2048);
+                        }
+                    }
+                    if constexpr (k == (NM > 1 ? 1 : 0)) {
+#pragma unroll
+                        for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                // DMAs issued R - 3 taps ago (and earlier) have landed -- and, behind an epilogue, its stores, which
+                // are older than this tap's DMAs (loads and stores retire in order)
+                constexpr int pending = [] {
+                    int n = 0;
+                    for (int k = 0; k < R - 3; ++k) {
+                        const int tt = (t - k + 9) % 9;
+                        for (int j = 0; j < D; ++j) n += (NW * j >= NB && tt >= ATAPS) ? 0 : 1;
+                    }
+                    return n;
+                }();
+                wait_vm<pending>();
+                // advance the weight stream; behind a tile's last slice comes the first one of the next tile
+                gwoff += wstep;
+                if (++gw == total) {
+                    gw = 0;
+                    gwoff = 0;
+                    w_tile = (unsigned)(n0n / 16) * 1024u;
+                    w_live = has_next;
                 }
-                if constexpr (ABL == 7) {
-                    if (v[0] + v[1] + v[2] + v[3] != 12345.678f) continue;
-                }
-                if (a.res) {
+            };
+            tap(tap_c<0>{});
+            tap(tap_c<1>{});
+            tap(tap_c<2>{});
+            tap(tap_c<3>{});
+            tap(tap_c<4>{});
+            tap(tap_c<5>{});
+            tap(tap_c<6>{});
+            tap(tap_c<7>{});
+            tap(tap_c<8>{});
+            abuf = abuf_next;
+        }
+
+        // ---- epilogue: bias, SiLU, residual; a lane holds 4 x 4 consecutive channels of one pixel per fragment.
+        // The next tile's first slices and input range are in flight meanwhile.
+        const int cq = kq * 4;
+        const bool wide = !a.out32 && ((a.out_cs | a.out_co) & 7) == 0;   // 16-byte stores need 8-channel alignment
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            const int m = m0 + (wm * MREP + i) * 32 + fr;
+            if (!wide) {
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int n = n0 + (wn * NREP + j) * 32 + gq * 8 + cq;
+                        const float4 b = *(const float4*)(a.bias + n);
+                        float v[4] = {acc[i][j][gq * 4 + 0] + b.x, acc[i][j][gq * 4 + 1] + b.y, acc[i][j][gq * 4 + 2] + b.z,
+                                      acc[i][j][gq * 4 + 3] + b.w};
+                        if (a.act) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = silu_t(v[r]);
+                        }
+                        if (a.res) {
+                            union {
+                                uint2 u;
+                                _Float16 h[4];
+                            } rr;
+                            rr.u = *(const uint2*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rr.h[r];
+                        }
+                        if (a.out32) {
+                            *(float4*)(a.out32 + (long)m * a.out_cs + a.out_co + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            union {
+                                uint2 u;
+                                _Float16 h[4];
+                            } o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o.h[r] = (_Float16)v[r];
+                            *(uint2*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + n) = o.u;
+                        }
+                    }
+                continue;
+            }
+            // f16 output in 16-byte pieces.  Channel groups gq and gq + 1 of a lane pair (l, l + 32) hold
+            // channels 8 gq + {0..3 | 4..7} and 8 gq + 8 + {0..3 | 4..7}: one v_permlane32_swap per dword
+            // gives the lower lane all eight channels of group gq and the upper lane those of group gq + 1.
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const int nb = n0 + (wn * NREP + j) * 32 + gp * 16;     // first channel of the pair of groups
+                    float v[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 b = *(const float4*)(a.bias + nb + h * 8 + cq);
+                        const int r0 = (gp * 2 + h) * 4;
+                        v[h * 4 + 0] = acc[i][j][r0 + 0] + b.x;
+                        v[h * 4 + 1] = acc[i][j][r0 + 1] + b.y;
+                        v[h * 4 + 2] = acc[i][j][r0 + 2] + b.z;
+                        v[h * 4 + 3] = acc[i][j][r0 + 3] + b.w;
+                    }
+                    if (a.act) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = silu_t(v[r]);
+                    }
+                    const int nl = nb + kq * 8;   // the eight channels this lane ends up with
                     union {
-                        uint2 u;
-                        _Float16 h[4];
-                    } rr;
-                    rr.u = *(const uint2*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rr.h[r];
-                }
-                if (a.out32) {
-                    *(float4*)(a.out32 + (long)m * a.out_cs + a.out_co + n) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    union {
-                        uint2 u;
-                        _Float16 h[4];
+                        uint4 u;
+                        _Float16 h[8];
+                        unsigned w[4];
                     } o;
+                    if (a.res) {
+                        // the shortcut is added in f32 before the one rounding, so the values are exchanged as f32
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o.h[r] = (_Float16)v[r];
-                    *(uint2*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + n) = o.u;
+                        for (int r = 0; r < 4; ++r) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[r]), __float_as_uint(v[4 + r]), false, false);
+                            v[r] = __uint_as_float(sw[0]);
+                            v[4 + r] = __uint_as_float(sw[1]);
+                        }
+                        // lower lane: v[0..3] own group gq, v[4..7] the upper lane's group gq; upper lane: v[0..3] the lower
+                        // lane's group gq + 1, v[4..7] own -- in both cases channels nl .. nl + 7 in order
+                        union {
+                            uint4 u;
+                            _Float16 h[8];
+                        } rr;
+                        if (m < a.M) rr.u = *(const uint4*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + nl);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o.h[r] = (_Float16)(v[r] + (float)rr.h[r]);
+                    } else {
+                        union {
+                            uint2 u;
+                            _Float16 h[4];
+                            unsigned w[2];
+                        } lo2, hi2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) lo2.h[r] = (_Float16)v[r], hi2.h[r] = (_Float16)v[4 + r];
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(lo2.w[0], hi2.w[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(lo2.w[1], hi2.w[1], false, false);
+                        o.w[0] = s0[0];
+                        o.w[1] = s1[0];
+                        o.w[2] = s0[1];
+                        o.w[3] = s1[1];
+                    }
+                    if constexpr (EPI == 0) {
+                        if (m < a.M) *(uint4*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + nl) = o.u;
+                    } else {
+                        *(uint4*)(smem + stg_base + fr * STG_PITCH + (j * 32 + gp * 16 + kq * 8) * 2) = o.u;
+                    }
+                }
+            if constexpr (EPI == 1) {
+                // the wave's 32 x (NREP * 32) block leaves as whole rows: NREP * 4 lanes per pixel
+                constexpr int CPP = NREP * 4;   // 16-byte chunks per pixel
+                const int mb = m0 + (wm * MREP + i) * 32;
+                const int nw0 = n0 + wn * NREP * 32;
+#pragma unroll
+                for (int it = 0; it < (32 * CPP) / 64; ++it) {
+                    const int f = it * 64 + lane;
+                    const int px = f / CPP, ch = f % CPP;
+                    const uint4 vv = *(const uint4*)(smem + stg_base + px * STG_PITCH + ch * 16);
+                    if (mb + px < a.M) *(uint4*)((_Float16*)a.out + (long)(mb + px) * a.out_cs + a.out_co + nw0 + ch * 8) = vv;
                 }
             }
         }
+
+        if (!has_next) break;
+        vb = vbn;
+        m0 = m0n;
+        n0 = n0n;
     }
+    wait_vm<0>();
 }
 
 struct T32Tile {
-    int bm, bn, threads, a_slots, ring;
-    void (*kernel)(const ConvArgs, int);
+    int bm, bn, threads, a_slots, ring, nrep, epi, wgs_per_cu;
+    void (*kernel)(const ConvArgs, int, int);
 };
 
-#define T32(WM, WN, MR, NR, AS, R) \
-    { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, conv_t32_kernel<WM, WN, MR, NR, AS, R> }
-#define T32A(WM, WN, MR, NR, AS, R, ABL) \
-    { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, conv_t32_kernel<WM, WN, MR, NR, AS, R, ABL> }
+#define T32(WM, WN, MR, NR, AS, R, EPI, WPC) \
+    { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, NR, EPI, WPC, conv_t32_kernel<WM, WN, MR, NR, AS, R, EPI> }
 
 const T32Tile kT32Tiles[] = {
-    T32(4, 2, 2, 3, 4, 5),    // 0: 256 x 192, 40-wide maps (22 input blocks over 6 taps), one workgroup per CU
-    T32(4, 2, 2, 3, 4, 4),    // 1: 256 x 192, up to 80-wide maps (27 blocks over 7 taps)
-    T32(8, 1, 2, 3, 10, 5),   // 2: 512 x 96
-    T32(4, 2, 2, 4, 8, 4),    // 3: 256 x 256 (fused head convs)
-    T32(8, 1, 2, 2, 12, 5),   // 4: 512 x 64
-    T32(4, 2, 1, 3, 4, 5),    // 5: 128 x 192
-    T32(8, 1, 1, 3, 10, 5),   // 6: 256 x 96
+    // one workgroup per CU (up to 256 VGPRs)
+    T32(4, 2, 2, 3, 4, 5, 1, 1),    // 0: 256 x 192, 40-wide maps (22 input blocks over 6 taps), rows leave through LDS
+    T32(4, 2, 2, 3, 4, 4, 1, 1),    // 1: 256 x 192, up to 80-wide maps (27 blocks over 7 taps)
+    T32(4, 2, 2, 3, 4, 5, 0, 1),    // 2: as 0 with lane-pair stores
+    T32(8, 1, 2, 3, 10, 5, 0, 1),   // 3: 512 x 96
+    T32(4, 2, 2, 4, 8, 4, 0, 1),    // 4: 256 x 256 (fused head convs)
+    T32(8, 1, 2, 2, 12, 5, 0, 1),   // 5: 512 x 64
     // two workgroups per CU (<= 128 VGPRs, <= 80 KiB of LDS): one's epilogue under the other's K loop
-    T32(8, 1, 1, 3, 10, 4),   // 7: 256 x 96
-    T32(8, 1, 1, 2, 12, 4),   // 8: 256 x 64
-    T32(8, 1, 1, 4, 8, 4),    // 9: 256 x 128
-    T32(4, 2, 1, 3, 4, 4),    // 10: 128 x 192
-    T32A(4, 2, 2, 3, 4, 5, 1),  // 11: ablation: no MFMA
-    T32A(8, 1, 1, 3, 10, 4, 1),  // 12: ablation of 7: no MFMA
-    T32A(8, 1, 1, 3, 10, 4, 3),  // 13: no DMA
-    T32A(8, 1, 1, 3, 10, 4, 4),  // 14: no barrier
-    T32A(4, 2, 2, 3, 4, 5, 5),  // 15: MFMA only
-    T32A(4, 2, 2, 3, 4, 5, 6),  // 16: MFMA + LDS reads
-    T32A(8, 1, 1, 3, 10, 4, 5),  // 17: MFMA only (2 WG/CU)
-    T32A(8, 1, 1, 3, 10, 4, 6),  // 18: MFMA + LDS reads (2 WG/CU)
-    T32A(4, 2, 2, 3, 4, 5, 7),  // 19: MFMA only, no stores
-    T32A(4, 2, 2, 3, 4, 5, 8),  // 20: MFMA only, no SiLU
-    T32A(4, 2, 2, 3, 4, 5, 9),  // 21: MFMA only, no epilogue
+    T32(8, 1, 1, 3, 10, 4, 0, 2),   // 6: 256 x 96
+    T32(8, 1, 1, 2, 12, 4, 0, 2),   // 7: 256 x 64
+    T32(4, 2, 1, 3, 4, 4, 0, 2),    // 8: 128 x 192
 };
 constexpr int kNumT32Tiles = sizeof(kT32Tiles) / sizeof(kT32Tiles[0]);
 
 int t32_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
-int t32_lds_bytes(const T32Tile& t, int W) { return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024; }
+int t32_lds_bytes(const T32Tile& t, int W) {
+    return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + (t.epi ? (t.threads / 64) * 32 * (t.nrep * 64 + 16) : 0);
+}
 
 }  // namespace
 
@@ -446,7 +536,7 @@ bool conv_t32_supported(const ConvArgs& a, int tile) {
     if (tile < 0) return true;
     const T32Tile& t = kT32Tiles[tile];
     const int na = t32_rows(t.bm, a.W) / 16;
-    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && t32_lds_bytes(t, a.W) <= 160 * 1024;
+    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && t32_lds_bytes(t, a.W) <= 160 * 1024 / t.wgs_per_cu;
 }
 
 void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
@@ -463,7 +553,9 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     });
     const int rows = t32_rows(t.bm, a.W);
     const int lds = t32_lds_bytes(t, a.W);
-    const int grid = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    const int n_tiles = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    // persistent: at most wgs_per_cu workgroups per CU (a multiple of 8: a workgroup stays on its XCD), each walks tiles
+    const int grid = std::min((n_tiles + 7) / 8 * 8, ctx.num_cus * t.wgs_per_cu);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
     static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
@@ -477,7 +569,7 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
         pname = names.emplace(buf, buf).first->second.c_str();
     }
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
-    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows);
+    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles);
     RMR_HIP(hipGetLastError());
 }
 

@@ -61,6 +61,7 @@ class Yolov8 {
     enum OpKind { OP_CONV, OP_SPPF, OP_UP, OP_HEAD };
     struct ConvW {
         DevBuf<__half> w;
+        DevBuf<__half> w32;  // 3x3 layers with Cin % 32 == 0: the LDS images conv_t32 streams (pack_conv_weights_t32)
         DevBuf<float> b;
         int cout = 0, cout_pad = 0, cin = 0, k = 0, K = 0, Kp = 0;
     };
@@ -86,6 +87,7 @@ class Yolov8 {
     // ci0 / ci_n: the slice of input channels to keep (ci_n = 0: all); no_bias: a zero bias
     int add_conv_weights(const WeightPack& p, const std::string& name, int cin_pad, int ci0 = 0, int ci_n = 0,
                          bool no_bias = false);
+    void upload_t32(ConvW& cw, const std::vector<__half>& packed);
     int add_fused_head_weights(const WeightPack& p, const std::string& a, const std::string& b);
     void conv(int widx, const View& in, const View& out, int stride, int act, const View* res = nullptr,
               bool out_f32 = false, bool in_is_input = false, const View* pre = nullptr);
@@ -115,6 +117,7 @@ class Yolov8 {
     // conv_dma tile, 200..299 conv_halo tile; + 1000 * split for split-K (conv_dma only)
     std::map<std::pair<int, int>, int> tuned_;
     bool autotune_ = true;
+    bool pinned_ = false;  // RMR_PLAN=<file>: kernels come from that plan, nothing is timed (reproducible outputs)
     bool tuned_dirty_ = false;
     // split-K workspace (partial tiles) and re-arming ticket counters, shared by all layers
     DevBuf<float> splitk_ws_;
@@ -138,6 +141,7 @@ class Yolov8 {
     std::string tune_path_;  // '<pack>.tune': choices persist like the reference's engine cache
     unsigned long long plan_signature() const;
     void load_tuning();
+    bool choice_supported(const ConvArgs& a, int choice) const;
     void save_tuning();
 };
 

@@ -16,12 +16,14 @@
 #include <algorithm>
 #include <cstdlib>
 #include <fstream>
+#include <unistd.h>
 
 #include "net_ops.h"
 
 namespace rmr {
 
 constexpr size_t kSplitKWsFloats = 16u << 20;  // 64 MiB of split-K partial tiles
+constexpr size_t kMaxViewBytes = 0xf0000000ull;  // largest activation view a buffer resource of the conv kernels addresses
 constexpr int kSplitKMaxTiles = 8192;
 
 // ---- weight pack ---------------------------------------------------------------------------------
@@ -29,6 +31,9 @@ constexpr int kSplitKMaxTiles = 8192;
 WeightPack WeightPack::load(const std::string& path) {
     std::ifstream f(path, std::ios::binary);
     if (!f) fail(RMR_ERR_INVALID_ARGUMENT, "weight pack '%s' does not exist or cannot be opened", path.c_str());
+    f.seekg(0, std::ios::end);
+    const size_t file_bytes = (size_t)f.tellg();
+    f.seekg(0, std::ios::beg);
     auto rd = [&](void* p, size_t n) {
         f.read((char*)p, (std::streamsize)n);
         if (!f) fail(RMR_ERR_RUNTIME, "weight pack '%s' is truncated", path.c_str());
@@ -58,7 +63,12 @@ WeightPack WeightPack::load(const std::string& path) {
         t.dims.resize(nd);
         rd(t.dims.data(), 4 * nd);
         size_t cnt = 1;
-        for (unsigned d : t.dims) cnt *= d;
+        for (unsigned d : t.dims) {
+            // a tensor cannot hold more floats than the file has bytes left: rejects corrupt dims before the
+            // product can wrap around size_t
+            if (d == 0 || cnt > file_bytes / 4 / d) fail(RMR_ERR_RUNTIME, "'%s': tensor '%s' is larger than the file", path.c_str(), name.c_str());
+            cnt *= d;
+        }
         t.data.resize(cnt);
         rd(t.data.data(), cnt * 4);
         p.tensors.emplace(std::move(name), std::move(t));
@@ -100,6 +110,8 @@ int Yolov8::add_conv_weights(const WeightPack& p, const std::string& name, int c
     const auto& b = p.get(name + ".bias");
     if (w.dims.size() != 4 || w.dims[2] != w.dims[3]) fail(RMR_ERR_RUNTIME, "tensor '%s.weight' is not OIkk", name.c_str());
     const int cin_all = (int)w.dims[1];
+    if (w.data.size() != (size_t)w.dims[0] * w.dims[1] * w.dims[2] * w.dims[3])
+        fail(RMR_ERR_RUNTIME, "tensor '%s.weight' does not hold its %u x %u x %u x %u values", name.c_str(), w.dims[0], w.dims[1], w.dims[2], w.dims[3]);
     if (ci_n == 0) ci0 = 0, ci_n = cin_all;
     if (ci0 < 0 || ci0 + ci_n > cin_all) fail(RMR_ERR_LOGIC, "conv '%s': channel slice outside the tensor", name.c_str());
     ConvW cw;
@@ -128,8 +140,18 @@ int Yolov8::add_conv_weights(const WeightPack& p, const std::string& name, int c
     cw.b.alloc(bias.size());
     RMR_HIP(hipMemcpy(cw.w.p, packed.data(), packed.size() * sizeof(__half), hipMemcpyHostToDevice));
     RMR_HIP(hipMemcpy(cw.b.p, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    upload_t32(cw, packed);
     convs_.push_back(std::move(cw));
     return (int)convs_.size() - 1;
+}
+
+// the second copy of a 3x3 layer's weights, as the LDS images conv_t32 streams
+void Yolov8::upload_t32(ConvW& cw, const std::vector<__half>& packed) {
+    if (cw.k != 3 || cw.cin % 32) return;
+    std::vector<__half> p32;
+    pack_conv_weights_t32(packed.data(), cw.cout_pad, cw.cin, cw.Kp, p32);
+    cw.w32.alloc(p32.size());
+    RMR_HIP(hipMemcpy(cw.w32.p, p32.data(), p32.size() * sizeof(__half), hipMemcpyHostToDevice));
 }
 
 // two convs over the same input, concatenated along Cout (Detect cv2.i.0 + cv3.i.0)
@@ -157,6 +179,7 @@ int Yolov8::add_fused_head_weights(const WeightPack& p, const std::string& a, co
     cw.b.alloc(bias.size());
     RMR_HIP(hipMemcpy(cw.w.p, packed.data(), packed.size() * sizeof(__half), hipMemcpyHostToDevice));
     RMR_HIP(hipMemcpy(cw.b.p, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    upload_t32(cw, packed);
     convs_.push_back(std::move(cw));
     return (int)convs_.size() - 1;
 }
@@ -164,9 +187,11 @@ int Yolov8::add_fused_head_weights(const WeightPack& p, const std::string& a, co
 void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act, const View* res,
                   bool out_f32, bool in_is_input, const View* pre) {
     const ConvW& cw = convs_[widx];
-    if (in.c != cw.cin) fail(RMR_ERR_LOGIC, "planner: conv %d expects %d input channels, view has %d", widx, cw.cin, in.c);
+    if (in.c != cw.cin)
+        fail(RMR_ERR_RUNTIME, "weight pack does not fit the network plan: conv %d consumes %d input channels, the plan feeds it %d (header scale vs tensors?)", widx, cw.cin, in.c);
     if (out.c != cw.cout_pad && !(out_f32 && out.cs == cw.cout_pad))
-        if (out.c != cw.cout) fail(RMR_ERR_LOGIC, "planner: conv %d produces %d channels, view has %d", widx, cw.cout, out.c);
+        if (out.c != cw.cout)
+            fail(RMR_ERR_RUNTIME, "weight pack does not fit the network plan: conv %d produces %d channels, the plan expects %d (header scale vs tensors?)", widx, cw.cout, out.c);
     Op op{};
     op.kind = OP_CONV;
     op.conv = widx;
@@ -390,17 +415,42 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
         a_off += f.h * f.w;
     }
 
+    // Images per launch: every activation view (pixels x its buffer's channel pitch, plus the span of its
+    // slabs) must stay below the 32-bit offset range of the kernels' buffer resources.  256 images of a
+    // 640 x 640 network are far below it; a 1920 x 1088 network is not.
+    {
+        size_t worst = 0;  // bytes per image of the largest view
+        for (const Op& op : ops_) {
+            for (const View* v : {&op.in, &op.out, &op.res}) {
+                if (!v->c && !v->cs) continue;
+                size_t bytes = (size_t)v->h * v->w * v->cs * sizeof(__half);
+                if (v == &op.in && op.in_slab_c) bytes += (size_t)(op.in.c / op.in_slab_c - 1) * op.in_slab_step * sizeof(__half);
+                if (v == &op.out && op.out_slab_c) bytes += (size_t)(op.out.c / op.out_slab_c - 1) * op.out_slab_step * sizeof(__half);
+                worst = std::max(worst, bytes);
+            }
+        }
+        worst = std::max(worst, (size_t)H * W * 8 * sizeof(__half));
+        const size_t fit = std::max<size_t>(1, kMaxViewBytes / std::max<size_t>(worst, 1));
+        if ((size_t)chunk_ > fit) chunk_ = (int)fit;
+    }
     splitk_ws_.alloc(kSplitKWsFloats);
     splitk_cnt_.alloc(kSplitKMaxTiles);
     RMR_HIP(hipMemset(splitk_cnt_.p, 0, kSplitKMaxTiles * sizeof(int)));
     tune_path_ = pack_path + ".tune";
-    if (autotune_) load_tuning();
+    if (const char* e = std::getenv("RMR_PLAN")) {
+        if (*e) {
+            tune_path_ = e;
+            pinned_ = true;
+            autotune_ = true;
+        }
+    }
     arena_.alloc(arena_halves_ * chunk_);
     arena32_.alloc(arena_floats_ * chunk_);
     input_.alloc((size_t)max_batch_ * H * W * 8);
     output_.alloc((size_t)max_batch_ * (4 + nc_) * anchors_);
     RMR_HIP(hipMemset(arena_.p, 0, arena_.n * sizeof(__half)));
     RMR_HIP(hipMemset(arena32_.p, 0, arena32_.n * sizeof(float)));
+    if (autotune_) load_tuning();  // after the arenas: cached choices are re-validated against the live layer arguments
 }
 
 // ---- executor ---------------------------------------------------------------------------------------
@@ -411,9 +461,11 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
 // (layer, batch) -- the analogue of the reference's TensorRT engine build (detector.cpp:177-243).
 void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     const int split = choice / 1000, c = choice % 1000;
-    if ((a.in_slab_c || a.out_slab_c) && (c < 700 || split))
+    if ((a.in_slab_c || a.out_slab_c) && (c < 700 || c >= 800 || split))
         fail(RMR_ERR_LOGIC, "kernel %d cannot address planar channel groups", choice);
-    if (c >= 700) {
+    if (c >= 800) {
+        launch_conv_t32(ctx_, s, a, c - 800);
+    } else if (c >= 700) {
         launch_conv_pw(ctx_, s, a, c - 700);
     } else if (c >= 600) {
         launch_conv_ws_s2(ctx_, s, a, c - 600);
@@ -451,6 +503,9 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (!a.pre && conv_halo_supported(a, -1))
         for (int t = 0; t < conv_halo_num_tiles(); ++t)
             if (conv_halo_supported(a, t)) cands.push_back(200 + t);
+    if (conv_t32_supported(a, -1))
+        for (int t = 0; t < conv_t32_num_tiles(); ++t)
+            if (conv_t32_supported(a, t)) cands.push_back(800 + t);
     // fragment-direct tiles only where the staged kernels cannot fill the chip
     if (!slabbed && conv_direct_supported(a, -1) && a.M <= 64 * ctx_.num_cus)
         for (int t = 0; t < conv_direct_num_tiles(); ++t)
@@ -565,36 +620,76 @@ unsigned long long Yolov8::plan_signature() const {
     return h;
 }
 
+// whether kernel `choice` can run layer `a` (what tune_conv would have offered): a cache line is only as
+// trustworthy as the file it came from
+bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
+    if (choice < 0) return false;
+    const int c = choice % 1000, split = choice / 1000;
+    const bool slabbed = a.in_slab_c || a.out_slab_c;
+    if (split) {
+        if (split > 64 || c < 100 || c >= 200 || slabbed || !conv_dma_supported(a) || c - 100 >= conv_dma_num_tiles()) return false;
+        const ConvTile ct = conv_dma_tile(c - 100);
+        return a.Cout_pad % ct.bn == 0 && conv_dma_splitk_tiles(a, c - 100) <= kSplitKMaxTiles &&
+               conv_dma_splitk_ws_floats(a, c - 100, split) <= kSplitKWsFloats;
+    }
+    if (c >= 800) return c - 800 < conv_t32_num_tiles() && conv_t32_supported(a, c - 800);
+    if (c >= 700) return c - 700 < conv_pw_num_variants() && conv_pw_supported(a, c - 700);
+    if (slabbed) return false;  // only conv_pw addresses planar channel groups
+    if (c >= 600) return !a.pre && c - 600 < conv_ws_s2_num_variants() && conv_ws_s2_supported(a, c - 600);
+    if (c == 500) return conv_stem_supported(a);
+    if (c >= 400) return c - 400 < conv_direct_num_tiles() && conv_direct_supported(a, c - 400);
+    if (c >= 300) return !a.pre && c - 300 < conv_ws_num_variants() && conv_ws_supported(a, c - 300);
+    if (c >= 200) return !a.pre && c - 200 < conv_halo_num_tiles() && conv_halo_supported(a, c - 200);
+    if (c >= 100) return c - 100 < conv_dma_num_tiles() && conv_dma_supported(a) && a.Cout_pad % conv_dma_tile(c - 100).bn == 0;
+    return c < conv_num_tiles() && a.Cout_pad % conv_tile(c).bn == 0;
+}
+
+// header: "rmr-tune <version> <ops> <w> <h> <plan signature> <CUs> <device name without blanks>"
+static std::string device_tag(int device) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return "unknown";
+    std::string n = p.gcnArchName;
+    for (char& ch : n)
+        if (ch == ' ' || ch == '\t') ch = '_';
+    return n.empty() ? "unknown" : n;
+}
+
 void Yolov8::load_tuning() {
+    // RMR_PLAN=<file>: a pinned plan -- the kernel per (layer, batch) comes from that file and nothing is ever
+    // timed, so two boxes (or two runs) launch the same kernels and produce bit-identical outputs
     std::ifstream f(tune_path_);
     if (!f) return;
-    std::string tag;
-    int version = 0, n_ops = 0, w = 0, h = 0;
+    std::string tag, dev;
+    int version = 0, n_ops = 0, w = 0, h = 0, cus = 0;
     unsigned long long sig = 0;
-    f >> tag >> version >> n_ops >> w >> h >> sig;
-    if (tag != "rmr-tune" || version != 9 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_ || sig != plan_signature())
+    f >> tag >> version >> n_ops >> w >> h >> sig >> cus >> dev;
+    if (tag != "rmr-tune" || version != 10 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_ || sig != plan_signature())
         return;
+    // timings from another chip say nothing about this one (a pinned plan is taken as it is)
+    if (!pinned_ && (cus != ctx_.num_cus || dev != device_tag(ctx_.device))) return;
     int op, n, choice;
     while (f >> op >> n >> choice) {
-        if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV) continue;
-        const int c = choice % 1000, split = choice / 1000;
-        const bool ok = choice >= 0 && split <= 64 && (split == 0 || (c >= 100 && c < 200)) &&
-                        (c >= 700 ? c - 700 < conv_pw_num_variants()
-                         : c >= 600 ? c - 600 < conv_ws_s2_num_variants()
-                         : c == 500 ? true
-                         : c >= 400 ? c - 400 < conv_direct_num_tiles()
-                         : c >= 300 ? c - 300 < conv_ws_num_variants()
-                         : c >= 200 ? c - 200 < conv_halo_num_tiles()
-                                  : c >= 100 ? c - 100 < conv_dma_num_tiles() : c < conv_num_tiles());
-        if (ok) tuned_[{op, n}] = choice;
+        if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV || n < 1 || n > chunk_) continue;
+        if (choice_supported(conv_args(op, n, 0), choice)) tuned_[{op, n}] = choice;
     }
 }
 
 void Yolov8::save_tuning() {
-    std::ofstream f(tune_path_, std::ios::trunc);
-    if (!f) return;  // read-only location: tune again next time
-    f << "rmr-tune 9 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << ' ' << plan_signature() << "\n";
-    for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
+    if (pinned_) return;
+    // one process per GPU may share a pack: write a private file, then rename it over the cache (atomic)
+    const std::string tmp = tune_path_ + ".tmp" + std::to_string((long)getpid());
+    {
+        std::ofstream f(tmp, std::ios::trunc);
+        if (!f) return;  // read-only location: tune again next time
+        f << "rmr-tune 10 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << ' ' << plan_signature() << ' ' << ctx_.num_cus << ' '
+          << device_tag(ctx_.device) << "\n";
+        for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
+        if (!f) {
+            std::remove(tmp.c_str());
+            return;
+        }
+    }
+    if (std::rename(tmp.c_str(), tune_path_.c_str()) != 0) std::remove(tmp.c_str());
 }
 
 ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
@@ -645,9 +740,18 @@ ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
     a.Kp = cw.Kp;
     a.M = n * a.Ho * a.Wo;
     a.act = op.act;
-    a.in_bytes = (unsigned)((size_t)n * a.H * a.W * a.in_cs * sizeof(__half) +
-                            (op.in_slab_c ? (size_t)(op.in.c / op.in_slab_c - 1) * op.in_slab_step * chunk_ * sizeof(__half) : 0));
+    const size_t in_bytes = (size_t)n * a.H * a.W * a.in_cs * sizeof(__half) +
+                            (op.in_slab_c ? (size_t)(op.in.c / op.in_slab_c - 1) * op.in_slab_step * chunk_ * sizeof(__half) : 0);
+    // the kernels address activations through 32-bit buffer offsets; the constructor sized chunk_ so that
+    // every view fits, this is the guard behind it (computed in 64 bits BEFORE it is narrowed)
+    if (in_bytes > kMaxViewBytes)
+        fail(RMR_ERR_CAPACITY, "conv %d: an input view of %zu bytes exceeds the 32-bit addressing of the conv kernels", op.conv, in_bytes);
+    a.in_bytes = (unsigned)in_bytes;
     a.wt_bytes = (unsigned)((size_t)cw.cout_pad * cw.Kp * sizeof(__half));
+    if (cw.w32.p) {
+        a.wt_t32 = cw.w32.p;
+        a.wt_t32_bytes = (unsigned)(cw.w32.n * sizeof(__half));
+    }
     a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
     return a;
 }
@@ -676,6 +780,9 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
             auto key = std::make_pair(op_index, n);
             auto it = tuned_.find(key);
             if (it == tuned_.end()) {
+                if (pinned_)
+                    fail(RMR_ERR_RUNTIME, "pinned plan '%s' has no kernel for layer %d at %d images (RMR_PLAN names a file written for this pack, input size and batch sizes)",
+                         tune_path_.c_str(), op_index, n);
                 it = tuned_.emplace(key, tune_conv(s, a)).first;
                 tuned_dirty_ = true;
             }

@@ -267,18 +267,24 @@ def test_conv_bad_arguments(rmr):
 
 
 def test_conv_t32_every_tile(rmr):
-    # 32x32x16-MFMA 3x3 / stride-1 kernel (conv_t32.hip): ids 800..; weights pre-packed as LDS images, fragment
-    # reads half a tap ahead of the MFMAs across the barrier, lane masks for the border taps
-    tiles = [(256, 192), (256, 192), (512, 96), (256, 256), (512, 64), (128, 192), (256, 96)]
+    # 32x32x16-MFMA 3x3 / stride-1 kernel (conv_t32.hip): ids 800..; persistent workgroups walking tiles with a
+    # continuous DMA stream, weights pre-packed as LDS images, fragment reads ahead of the MFMAs across the
+    # barrier, lane masks for the border taps, 16-byte stores (lane-pair exchange or rows staged through LDS)
+    tiles = [(256, 192), (256, 192), (256, 192), (512, 96), (256, 256), (512, 64), (256, 96), (256, 64), (128, 192)]
     for t, (bm, bn) in enumerate(tiles):
         run_case(rmr, 3, 20, 20, 64, bn, 3, 1, True, True, tile=800 + t, seed=t)            # 3 images in ~5 tiles
         run_case(rmr, 1, 19, 23, 32, bn * 2, 3, 1, True, False, tile=800 + t, seed=40 + t)  # odd W, ragged M, 1 chunk
     run_case(rmr, 2, 40, 40, 192, 192, 3, 1, True, True, tile=800, seed=70)   # 6 chunks, 54 taps
     run_case(rmr, 1, 80, 80, 192, 192, 3, 1, True, False, tile=801, seed=71)  # W = 80: 27 input blocks
-    run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, True, tile=802, seed=72)     # 512-row tiles on 80-wide maps
-    run_case(rmr, 2, 20, 20, 288, 288, 3, 1, True, True, tile=802, seed=73)   # 9 chunks, 3 channel tiles
+    run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, True, tile=803, seed=72)     # 512-row tiles on 80-wide maps
+    run_case(rmr, 2, 20, 20, 288, 288, 3, 1, True, True, tile=806, seed=73)   # 9 chunks, 3 channel tiles
     run_case(rmr, 1, 5, 5, 32, 96, 3, 1, False, False, tile=806, seed=74)     # tile far larger than the image
-    run_case(rmr, 5, 40, 40, 96, 256, 3, 1, True, False, tile=803, seed=75)   # fused head conv shape
+    run_case(rmr, 5, 40, 40, 96, 256, 3, 1, True, False, tile=804, seed=75)   # fused head conv shape
+    # more tiles than workgroups: every workgroup walks several tiles (the stream crosses tile boundaries,
+    # the channel tile changes under it)
+    run_case(rmr, 160, 20, 20, 32, 192, 3, 1, True, True, tile=806, seed=76)  # 250 x 2 tiles of 256 x 96 on 512 slots... and
+    run_case(rmr, 300, 20, 20, 32, 192, 3, 1, True, True, tile=802, seed=77)  # 469 tiles of 256 x 192 on 256 workgroups
+    run_case(rmr, 330, 20, 20, 32, 96, 3, 1, True, False, tile=806, seed=78)  # 516 tiles on 512 workgroups: a few walk two
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 4, 4, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
                    False, tile=806)  # Cin = 48 is not a multiple of 32
