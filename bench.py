@@ -17,8 +17,19 @@ boxes, so CROPS fixed crop rects per frame are injected for the armor stage -- t
 runs in full (forward + decode + NMS).  Multi-GPU: streams shard across ranks (weak scaling: every
 rank processes its own BATCH frames per step), no data-path collective.
 
-Prints ONE JSON line (rank 0).  Extra keys: p50_ms_batch1 (latency of one frame incl. H2D),
-roofline (dominant kernel = conv_igemm_f16, HIP events on its own stream), cpu_baseline.
+Measurement layout (one process):
+  1. untimed: tuning call + W warm-up steps;
+  2. HEADLINE: exactly K steps, no profiling events anywhere, barrier + synchronize on both sides -> value;
+  3. steady state: further un-profiled steps until --seconds have been timed in total (the driver's 20 steps
+     are under a second; SURVEY 8d asks for >= 10 s) -> steady_state;
+  4. roofline: a few more steps with HIP events around every convolution launch on the stream it runs on,
+     named per GEMM shape -> roofline (dominant kernel family) and layer_roofline (every layer against
+     max(FLOPs / MFMA peak, algorithmic bytes / HBM peak));
+  5. H2D: the step's inputs (frames + clouds) copied from pinned host memory, timed on their own ->
+     h2d_ms_per_step and value_incl_h2d (never `value`: inputs are resident in HBM in the timed region);
+  6. batch-1 latency with host inputs; the CPU baseline on a bounded sample.
+
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -32,7 +43,25 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
+os.environ.setdefault("RMR_PROFILE_LAYERS", "1")  # per-GEMM-shape names in the profiled loop (read when librmr loads)
+
 F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 MFMA
+HBM_PEAK_TBS = 8.0              # MI355X_MICROARCH.md: 8 TB/s (6.3 achievable)
+# what a chip-filling loop of nothing but v_mfma_f32_32x32x16_f16 delivers on random f16 operands before the
+# power limit clocks it down (tools/microbench/mfma_power.hip, profiles/r02_mfma_power.txt); zeros: 2400
+F16_POWER_LIMITED_TFLOPS = 1650.0
+
+
+def source_hash():
+    """Hash of the kernel sources: profiles/*_pmc_conv_traffic.json records the one it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rm_radar_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -48,8 +77,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
-    ap.add_argument("--no-profile", action="store_true", help="time the steps without per-kernel HIP events")
-    return ap.parse_args()
+    ap.add_argument("--no-profile", action="store_true", help="skip the profiled loop (no roofline objects)")
+    ap.add_argument("--seconds", type=float, default=10.0, help="steady state: keep stepping until this much time is measured")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE configs index: 2 = 640x640 + 30k points; 3 = one 1920x1080 "
+                    "stream + 100k-point clouds per GPU")
+    args = ap.parse_args()
+    if args.config == 3:
+        args.size, args.height, args.points = 1920, 1080, 100000
+    return args
 
 
 def frame_size(args):
@@ -206,45 +242,95 @@ def main():
     sync_all()
     for k in phases:
         phases[k] = 0.0
-    if args.no_profile:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            block, counts = step()
-        sync_all()
-        dt = time.perf_counter() - t0
-        stats = {}
-    else:
-        # events only around the convolution launches (the roofline kernel family): events on every
-        # launch of every stream cost the step 3 % (per-kernel times of the rest: profiles/*kernel_stats*)
-        with rmr.profile(local, flops_only=True) as prof:
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                block, counts = step()
-            sync_all()
-            dt = time.perf_counter() - t0
-            stats = prof.read()
+    # ---- 2. headline: exactly K steps, nothing profiled -------------------------------------------------
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        block, counts = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    headline_phases = {k: v for k, v in phases.items()}
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # ---- 3. steady state: the same loop until --seconds are on the clock (all ranks run the same count)
+    steady = None
+    if args.seconds > dt:
+        extra = max(1, int((args.seconds - dt) / (dt / args.steps) + 0.5))
+        t0 = time.perf_counter()
+        for _ in range(extra):
+            step()
+        sync_all()
+        dt2 = time.perf_counter() - t0
+        t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt2 = float(t.item())
+        steady = {"steps": args.steps + extra, "seconds": round(dt + dt2, 3),
+                  "value": round(B * (args.steps + extra) * world / (dt + dt2), 2), "unit": "frames/s"}
+
+    # ---- 4. roofline: events around the convolution launches only, per GEMM shape ------------------------
+    stats = {}
+    if not args.no_profile:
+        with rmr.profile(local, flops_only=True) as prof:
+            for _ in range(args.profile_steps):
+                step()
+            sync_all()
+            stats = prof.read()
+
+    # ---- 5. the step's inputs over PCIe, on their own -----------------------------------------------------
+    h2d_ms = None
+    if rank == 0:
+        p_img = torch.from_numpy(images).pin_memory()
+        p_cld = torch.from_numpy(clouds).pin_memory()
+        for _ in range(2):
+            d_images.copy_(p_img, non_blocking=True)
+            d_clouds.copy_(p_cld, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            d_images.copy_(p_img, non_blocking=True)
+            d_clouds.copy_(p_cld, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t0) / 5 * 1e3
+        del p_img, p_cld
+
     n_located = int(((block.view(-1, 12)[:, 9] & 2) != 0).sum().item()) if block.numel() else 0
-    # HBM traffic per conv launch: PMC counters cannot be read from inside this process; the figure
-    # comes from the committed rocprofv3 --pmc passes over this same command (profiles/)
-    traffic, traffic_src = None, None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
-        if B == 64 and K == 4 and size == (640, 640):
-            traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/r01_pmc_conv_traffic.json"
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM traffic per conv launch: PMC counters cannot be read from inside this process; the figure comes from
+    # rocprofv3 --pmc passes over this same command (tools/round_profile.sh) and is only as fresh as the kernel
+    # sources it was measured on: the file records their hash, a mismatch is reported as stale
+    traffic, traffic_src, traffic_stale = None, None, None
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_conv_traffic.json")), reverse=True):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if B == 64 and K == 4 and size == (640, 640):
+                traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/" + name
+                traffic_stale = pm.get("source_hash") != source_hash()
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     result = None
     if rank == 0:
         frames = B * args.steps * world
-        conv = stats.get("conv_igemm_f16", {"total_ms": 0.0, "flops": 0.0, "launches": 0})
+        convs = {k: v for k, v in stats.items() if v["flops"] > 0}
+        conv = {"total_ms": sum(v["total_ms"] for v in convs.values()), "flops": sum(v["flops"] for v in convs.values()),
+                "bytes": sum(v["bytes"] for v in convs.values()), "launches": sum(v["launches"] for v in convs.values())}
         ach = conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0
-        kernels = {k: {"launches": v["launches"], "ms_per_step": round(v["total_ms"] / args.steps, 4)}
-                   for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
+        psteps = max(args.profile_steps, 1)
+        # every layer against its own bound: the time the chip needs at the MFMA peak or at the HBM peak,
+        # whichever is larger; summed over the step
+        bound_ms = sum(max(v["flops"] / (F16_DENSE_PEAK_TFLOPS * 1e12), v["bytes"] / (HBM_PEAK_TBS * 1e12)) * 1e3 for v in convs.values())
+        top = sorted(convs.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
+        layer_roofline = {
+            "peaks": {"mfma_tflops": F16_DENSE_PEAK_TFLOPS, "hbm_tbs": HBM_PEAK_TBS},
+            "bound_ms_per_step": round(bound_ms / psteps, 3), "measured_ms_per_step": round(conv["total_ms"] / psteps, 3),
+            "frac": round(bound_ms / conv["total_ms"], 4) if conv["total_ms"] > 0 else None,
+            "layers": len(convs),
+            "top": [{"layer": k, "launches_per_step": v["launches"] / psteps, "ms_per_step": round(v["total_ms"] / psteps, 3),
+                     "tflops": round(v["flops"] / v["total_ms"] / 1e9, 1), "gbs": round(v["bytes"] / v["total_ms"] / 1e6),
+                     "bound": "mfma" if v["flops"] / F16_DENSE_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_TBS / 1e12 else "hbm"}
+                    for k, v in top]}
         result = {
             "metric": "frames/sec detect+locate (640x640 + 30k-pt cloud)",
             "value": frames / dt,
@@ -258,22 +344,28 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": f"{'configs[2]' if size == (640, 640) else 'configs[3] shape'}: batch={B} synthetic {size[0]}x{size[1]} frames + "
+            "config": {"workload": f"{'configs[2]' if size == (640, 640) else 'configs[3]: one stream per GPU,'}: batch={B} synthetic {size[0]}x{size[1]} frames + "
                                    f"{args.points}-pt clouds per step per GPU, car YOLOv8m + {K} injected "
                                    f"armor crops/frame (YOLOv8m, nc=12), seeded synthetic weights, f16 MFMA",
                        "frames_per_step_per_gpu": B, "crops_per_frame": K, "points_per_cloud": args.points,
                        "streams_per_gpu": 1, "gflop_per_frame": round(flops_frame / 1e9, 3)},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f16", "achieved": round(ach, 2),
+            "roofline": {"bound": "mfma", "kernel": "conv_* (the convolution launches of a step)", "achieved": round(ach, 2),
                          "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": round(conv.get("bytes", 0.0) / max(conv["launches"], 1)),
-                         "launches_per_step": conv["launches"] / max(args.steps, 1),
+                         "frac": round(ach / F16_DENSE_PEAK_TFLOPS, 4),
+                         "power_limited_peak": F16_POWER_LIMITED_TFLOPS,
+                         "frac_of_power_limited_peak": round(ach / F16_POWER_LIMITED_TFLOPS, 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "algorithmic_bytes_per_launch": round(conv["bytes"] / max(conv["launches"], 1)),
+                         "launches_per_step": conv["launches"] / psteps,
                          "avg_launch_ms": round(conv["total_ms"] / max(conv["launches"], 1), 5),
-                         "algorithmic_gflop_per_launch": round(conv["flops"] / max(conv["launches"], 1) / 1e9, 4)},
-            "kernels": kernels,
+                         "algorithmic_gflop_per_launch": round(conv["flops"] / max(conv["launches"], 1) / 1e9, 4),
+                         "measured_in": f"{psteps} profiled step(s) after the headline loop (events on the detector's streams)"},
+            "layer_roofline": layer_roofline,
+            "steady_state": steady,
+            "h2d_ms_per_step": None if h2d_ms is None else round(h2d_ms, 3),
+            "value_incl_h2d": None if h2d_ms is None else round(B * world / (dt / args.steps + h2d_ms * 1e-3), 2),
             "end_to_end_tflops": round(flops_frame * frames / dt / 1e12, 2),
-            "host_phase_ms_per_step": {k: round(v / args.steps * 1e3, 2) for k, v in phases.items()},
+            "host_phase_ms_per_step": {k: round(v / args.steps * 1e3, 2) for k, v in headline_phases.items()},
             "located_last_step": n_located,
         }
 

@@ -18,7 +18,8 @@ void robot_set_detection(rmr_robot& r, const rmr_detection& car, const rmr_detec
     r.rect[3] = car.height;
     r.label = -1;
     if (n_armors <= 0) return;
-    n_armors = std::min(n_armors, (int)RMR_MAX_ARMORS);
+    // label, confidence (and through them the tracker feature) are voted by ALL armors, as in the
+    // reference; only the stored list is bounded by the struct (RMR_MAX_ARMORS)
 
     // std::map<int, float>: per-label confidence sums, accumulated in armor order
     std::map<int, float> score;
@@ -37,9 +38,9 @@ void robot_set_detection(rmr_robot& r, const rmr_detection& car, const rmr_detec
     r.has_label = 1;
     r.label = label;
     r.confidence = confidence;
-    r.n_armors = n_armors;
+    r.n_armors = std::min(n_armors, (int)RMR_MAX_ARMORS);
     // armor boxes move from crop coordinates to image coordinates (robot.cpp:69-73)
-    for (int i = 0; i < n_armors; ++i) {
+    for (int i = 0; i < r.n_armors; ++i) {
         r.armors[i] = armors[i];
         r.armors[i].x += car.x;
         r.armors[i].y += car.y;

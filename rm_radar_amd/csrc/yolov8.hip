@@ -438,8 +438,8 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     RMR_HIP(hipMemset(splitk_cnt_.p, 0, kSplitKMaxTiles * sizeof(int)));
     tune_path_ = pack_path + ".tune";
     if (const char* e = std::getenv("RMR_PLAN")) {
-        if (*e) {
-            tune_path_ = e;
+        if (*e && std::strcmp(e, "0") != 0) {
+            if (std::strcmp(e, "1") != 0) tune_path_ = e;  // "1": the pack's own '<pack>.tune', taken as it is
             pinned_ = true;
             autotune_ = true;
         }

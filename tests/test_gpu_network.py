@@ -234,7 +234,16 @@ def test_robot_detector_matches_oracle(rmr, oracle, packs, refs, images):
     # forced crops: robots carry the injected rects
     fc = [[(10, 20, 200, 150), (300, 300, 100, 120)]]
     gf = rd.detect_batch([img], forced_crops=fc)
-    assert sorted(r.rect for r in gf[0]) == sorted((float(a), float(b), float(c), float(d)) for a, b, c, d in fc[0]) or len(gf[0]) <= 2
+    want_rects = sorted((float(a), float(b), float(c), float(d)) for a, b, c, d in fc[0])
+    # detector.cpp:427-454 keeps every robot without armors and ONE robot per armor label (the std::map):
+    # the survivors carry injected rects, no rect twice, no label twice, and a robot can only be missing
+    # because another one with its label survived
+    got_rects = sorted(r.rect for r in gf[0])
+    assert 1 <= len(got_rects) <= 2 and len(set(got_rects)) == len(got_rects) and set(got_rects) <= set(want_rects)
+    labels = [r.label for r in gf[0] if r.label is not None]
+    assert len(labels) == len(set(labels))
+    if len(got_rects) < 2:
+        assert labels, "an unlabelled robot is never dropped (detector.cpp:432-435)"
     rd.close()
 
 

@@ -3,9 +3,13 @@
 WRITE_SIZE collected separately, as MI355X_MICROARCH.md prescribes) -> profiles/rNN_pmc_conv_traffic.json.
 usage: tools/pmc_traffic.py fetch.db write.db out.json "<command that was profiled>" """
 import json
+import os
 import sqlite3
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (the kernel sources this measurement belongs to)
 
 
 def per_launch(db, counter):
@@ -30,8 +34,9 @@ def per_launch(db, counter):
 fetch_kb, n_f, cols = per_launch(sys.argv[1], "FETCH_SIZE")
 write_kb, n_w, _ = per_launch(sys.argv[2], "WRITE_SIZE")
 out = {
-    "round": 1,
-    "kernel": "conv_* (all instantiations of conv_igemm / conv_dma / conv_halo / conv_ws / conv_ws_s2 / conv_pw / conv_stem / conv_direct)",
+    "round": 2,
+    "source_hash": source_hash(),
+    "kernel": "conv_* (all instantiations of conv_igemm / conv_dma / conv_halo / conv_t32 / conv_ws / conv_ws_s2 / conv_pw / conv_stem / conv_direct)",
     "command": sys.argv[4] if len(sys.argv) > 4 else "",
     "launches_counted": n_f,
     "FETCH_SIZE_kb_per_launch": fetch_kb,
