@@ -186,6 +186,11 @@ rmr_status rmr_detector_detect(rmr_detector* det, const rmr_image* imgs, const i
  * HOST [n][4+classes][anchors] f32 (detector.cpp:129-130); pp[n] optional. */
 rmr_status rmr_detector_infer(rmr_detector* det, const rmr_image* imgs, const int* crops, int n,
                               float* net_out, rmr_preparam* pp);
+/* Parity hook: the output of backbone / neck stage `name` ("model.0" ... "model.21", Ultralytics module names)
+ * for image `img` of the detector's last call, as HOST f32 [h][w][c]; dims = {h, w, c}; out may be NULL
+ * (dimensions only).  RMR_ERR_INVALID_ARGUMENT for an unknown stage.  TensorRT offers the same through
+ * marked network outputs (detector.cpp:187-231 builds the network from the ONNX graph). */
+rmr_status rmr_detector_read_feature(rmr_detector* det, const char* name, int img, float* out, int* dims);
 int rmr_detector_anchors(const rmr_detector* det);
 int rmr_detector_channels(const rmr_detector* det);
 /* algorithmic FLOPs of one 640x640 forward (2*MAC over all convs) */

@@ -67,28 +67,44 @@ class YoloV8Ref:
         y3 = F.max_pool2d(y2, 5, 1, 2)
         return self.conv(f"{name}.cv2.conv", torch.cat([x, y1, y2, y3], 1), 1)
 
-    def backbone_neck(self, x):
+    def backbone_neck(self, x, keep=None):
+        """keep: a dict that receives every stage output by Ultralytics module name ("model.0" ... "model.21")"""
         a = self.arch
         n = a["n"]
-        x = self.conv("model.0.conv", x, 3, 2)
-        x = self.conv("model.1.conv", x, 3, 2)
-        x = self.c2f("model.2", x, n[0], True)
-        x = self.conv("model.3.conv", x, 3, 2)
-        p3 = self.c2f("model.4", x, n[1], True)
-        x = self.conv("model.5.conv", p3, 3, 2)
-        p4 = self.c2f("model.6", x, n[2], True)
-        x = self.conv("model.7.conv", p4, 3, 2)
-        x = self.c2f("model.8", x, n[3], True)
-        p5 = self.sppf("model.9", x)
+
+        def k(name, t):
+            if keep is not None:
+                keep[name] = t
+            return t
+        x = k("model.0", self.conv("model.0.conv", x, 3, 2))
+        x = k("model.1", self.conv("model.1.conv", x, 3, 2))
+        x = k("model.2", self.c2f("model.2", x, n[0], True))
+        x = k("model.3", self.conv("model.3.conv", x, 3, 2))
+        p3 = k("model.4", self.c2f("model.4", x, n[1], True))
+        x = k("model.5", self.conv("model.5.conv", p3, 3, 2))
+        p4 = k("model.6", self.c2f("model.6", x, n[2], True))
+        x = k("model.7", self.conv("model.7.conv", p4, 3, 2))
+        x = k("model.8", self.c2f("model.8", x, n[3], True))
+        p5 = k("model.9", self.sppf("model.9", x))
         up = F.interpolate(p5, scale_factor=2, mode="nearest")
-        h4 = self.c2f("model.12", torch.cat([up, p4], 1), a["nh"], False)
+        h4 = k("model.12", self.c2f("model.12", torch.cat([up, p4], 1), a["nh"], False))
         up = F.interpolate(h4, scale_factor=2, mode="nearest")
-        o3 = self.c2f("model.15", torch.cat([up, p3], 1), a["nh"], False)
+        o3 = k("model.15", self.c2f("model.15", torch.cat([up, p3], 1), a["nh"], False))
         x = self.conv("model.16.conv", o3, 3, 2)
-        o4 = self.c2f("model.18", torch.cat([x, h4], 1), a["nh"], False)
+        o4 = k("model.18", self.c2f("model.18", torch.cat([x, h4], 1), a["nh"], False))
         x = self.conv("model.19.conv", o4, 3, 2)
-        o5 = self.c2f("model.21", torch.cat([x, p5], 1), a["nh"], False)
+        o5 = k("model.21", self.c2f("model.21", torch.cat([x, p5], 1), a["nh"], False))
         return [o3, o4, o5]
+
+    @torch.no_grad()
+    def features(self, blob):
+        """Every stage output of the backbone and neck for blob [B,3,H,W]: name -> [B,H,W,C] numpy (NHWC)."""
+        x = torch.from_numpy(np.ascontiguousarray(blob, np.float32))
+        if self.f16:
+            x = _r16(x)
+        keep = {}
+        self.backbone_neck(x, keep)
+        return {name: t.permute(0, 2, 3, 1).contiguous().numpy() for name, t in keep.items()}
 
     def head_logits(self, feats):
         """-> (box logits [B,64,A], class logits [B,nc,A]) in P3,P4,P5 anchor order"""

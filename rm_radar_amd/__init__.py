@@ -19,7 +19,7 @@ from ._lib import (CapacityError, DET_DTYPE, DeviceError, InvalidArgument, PrePa
 
 __all__ = ["Detector", "RobotDetector", "Locator", "Robot", "PreParam", "preparam", "FrameBatch",
            "letterbox_geometry", "letterbox", "preprocess", "postprocess", "transpose",
-           "conv2d", "restore_detection", "device_count", "profile", "DET_DTYPE", "RmrError",
+           "conv2d", "pin_plan", "restore_detection", "device_count", "profile", "DET_DTYPE", "RmrError",
            "run_batch", "Tracker", "KalmanFilter", "SingerEKF", "auction", "TRACK_TENTATIVE", "TRACK_CONFIRMED", "TRACK_DELETED",
            "InvalidArgument", "DeviceError", "CapacityError", "Label"]
 
@@ -153,6 +153,29 @@ def conv2d(x_nhwc, w_oihw, bias, stride, pad, silu, residual=None, tile=-1, devi
                            stride, pad, int(bool(silu)), _lib.fp(r) if r is not None else None,
                            _lib.fp(y), tile))
     return y
+
+
+def pin_plan(tune_path, plan_path, batches):
+    """Write a pinned plan (RMR_PLAN=<plan_path>) from a tuning cache: every layer runs, at each batch size in
+    `batches`, the kernel the cache chose for its LARGEST tuned batch.  One kernel per layer whatever the batch
+    means one f32 summation order per output value, so an image gives bit-identical results alone or inside
+    a batch; and nothing is timed when a plan is pinned, so two boxes launch the same kernels."""
+    with open(tune_path) as f:
+        header = f.readline()
+        best = {}
+        for line in f:
+            op, n, choice = (int(v) for v in line.split())
+            # split-K (1000 * split + tile) reduces partial sums in an order that depends on the split: the
+            # plan takes the same tile without it
+            choice %= 1000
+            if op not in best or n > best[op][0]:
+                best[op] = (n, choice)
+    with open(plan_path, "w") as f:
+        f.write(header)
+        for op, (_, choice) in sorted(best.items()):
+            for n in batches:
+                f.write(f"{op} {n} {choice}\n")
+    return plan_path
 
 
 def conv_bench(n, h, w, cin, cout, k, stride, kernel, residual=False, reps=10, device=0):
@@ -290,6 +313,15 @@ class Detector:
         check(lib().rmr_detector_detect(self._h, arr, cr, n, out.ctypes.data, _lib.ip(counts), cap))
         res = [out[i, :counts[i]].copy() for i in range(n)]
         return res[0] if single else res
+
+    def read_feature(self, name, img=0):
+        """Output of backbone / neck stage `name` ("model.0" ... "model.21") for image `img` of the last call,
+        f32 [h, w, c] (parity hook)."""
+        dims = np.zeros(3, np.int32)
+        check(lib().rmr_detector_read_feature(self._h, name.encode(), img, None, _lib.ip(dims)))
+        out = np.empty(tuple(int(v) for v in dims), np.float32)
+        check(lib().rmr_detector_read_feature(self._h, name.encode(), img, _lib.fp(out), _lib.ip(dims)))
+        return out
 
     def infer(self, images, crops=None):
         """preprocess + network: the [n, 4+classes, anchors] tensor handed to postprocess."""

@@ -48,6 +48,15 @@ rmr_status rmr_detector_infer(rmr_detector* det, const rmr_image* imgs, const in
     });
 }
 
+rmr_status rmr_detector_read_feature(rmr_detector* det, const char* name, int img, float* out, int* dims) {
+    return guarded([&] {
+        if (!det || !name || !dims) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_detector_read_feature: null argument");
+        det->impl.ctx().use();
+        if (!det->impl.net().read_feature(det->impl.stream(), name, img, out, dims))
+            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_detector_read_feature: no stage named '%s'", name);
+    });
+}
+
 int rmr_detector_anchors(const rmr_detector* det) { return det ? const_cast<rmr_detector*>(det)->impl.net().anchors() : 0; }
 int rmr_detector_channels(const rmr_detector* det) { return det ? const_cast<rmr_detector*>(det)->impl.net().channels() : 0; }
 double rmr_detector_flops_per_image(const rmr_detector* det) {

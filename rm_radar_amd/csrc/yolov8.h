@@ -45,6 +45,10 @@ class Yolov8 {
     int channels() const { return 4 + nc_; }
     double flops_per_image() const { return flops_; }
     int max_batch() const { return max_batch_; }
+    // Debug / parity hook: the output of a backbone / neck stage ("model.0" ... "model.21") of image `img` of
+    // the last forward(), as f32 [h][w][c] on the host (out = nullptr: the dimensions only).  The arena never
+    // reuses memory, so every stage output is still there after a forward.
+    bool read_feature(hipStream_t s, const std::string& name, int img, float* out, int dims[3]);
 
     // network input: f16 NHWC with 8 channels per pixel (RGB + 5 zero lanes), [max_batch]
     __half* input() { return input_.p; }
@@ -108,6 +112,12 @@ class Yolov8 {
     double flops_ = 0;
     std::vector<ConvW> convs_;
     std::vector<Op> ops_;
+    struct Named {
+        View v;
+        int slab_c = 0;        // planar channel groups (0: interleaved)
+        size_t slab_step = 0;
+    };
+    std::map<std::string, Named> named_;  // stage outputs by Ultralytics module name
     size_t arena_halves_ = 0, arena_floats_ = 0;  // per image
     DevBuf<__half> arena_;
     DevBuf<float> arena32_;

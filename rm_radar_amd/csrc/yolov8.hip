@@ -332,25 +332,34 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     x0.w = W;
     View l0 = alloc(H / 2, W / 2, ch[0]);
     conv(add_conv_weights(p, "model.0.conv", 8), x0, l0, 2, 1, nullptr, false, true);
+    named_["model.0"] = {l0};
     View l1 = alloc(H / 4, W / 4, ch[1]);
     conv(add_conv_weights(p, "model.1.conv", 0), l0, l1, 2, 1);
+    named_["model.1"] = {l1};
     View l2 = c2f(p, "model.2", l1, n0, true, nullptr);
+    named_["model.2"] = {l2};
     View l3 = alloc(H / 8, W / 8, ch[2]);
     conv(add_conv_weights(p, "model.3.conv", 0), l2, l3, 2, 1);
+    named_["model.3"] = {l3};
     // the two nearest-neighbour upsamples feed 1x1 convolutions only: folded into them (c2f) where the
     // channel counts suit the kernels that carry the addend; the concat buffers then hold the skip alone
     const bool fold11 = fuse_up_ && ch[4] % 32 == 0 && ch[3] % 32 == 0, fold14 = fuse_up_ && ch[3] % 32 == 0 && ch[2] % 32 == 0;
     View cat14 = alloc(H / 8, W / 8, fold14 ? ch[2] : ch[3] + ch[2]);  // [up(model.12), model.4]
     View l4v = fold14 ? cat14 : slice(cat14, ch[3], ch[2]);
     View l4 = c2f(p, "model.4", l3, n1, true, &l4v);
+    named_["model.4"] = {l4};
     View l5 = alloc(H / 16, W / 16, ch[3]);
     conv(add_conv_weights(p, "model.5.conv", 0), l4, l5, 2, 1);
+    named_["model.5"] = {l5};
     View cat11 = alloc(H / 16, W / 16, fold11 ? ch[3] : ch[4] + ch[3]);  // [up(model.9), model.6]
     View l6v = fold11 ? cat11 : slice(cat11, ch[4], ch[3]);
     View l6 = c2f(p, "model.6", l5, n2, true, &l6v);
+    named_["model.6"] = {l6};
     View l7 = alloc(H / 32, W / 32, ch[4]);
     conv(add_conv_weights(p, "model.7.conv", 0), l6, l7, 2, 1);
+    named_["model.7"] = {l7};
     View l8 = c2f(p, "model.8", l7, n3, true, nullptr);
+    named_["model.8"] = {l8};
     // SPPF
     const int cs = ch[4] / 2;
     if (cs % 8) fail(RMR_ERR_RUNTIME, "SPPF hidden width %d is not a multiple of 8", cs);
@@ -365,6 +374,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     View cat20 = alloc(H / 32, W / 32, ch[3] + ch[4]);  // [model.19, model.9]
     View l9 = slice(cat20, ch[3], ch[4]);
     conv(add_conv_weights(p, "model.9.cv2.conv", 0), spp, l9, 1, 1);
+    named_["model.9"] = {l9};
     // neck
     const auto upsample = [&](const View& in, const View& out) {
         Op op{};
@@ -377,12 +387,16 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     View cat17 = alloc(H / 16, W / 16, ch[2] + ch[3]);  // [model.16, model.12]
     View l12v = slice(cat17, ch[2], ch[3]);
     View l12 = c2f(p, "model.12", cat11, nh, false, &l12v, fold11 ? &l9 : nullptr);
+    named_["model.12"] = {l12};
     if (!fold14) upsample(l12, slice(cat14, 0, ch[3]));
     View l15 = c2f(p, "model.15", cat14, nh, false, nullptr, fold14 ? &l12 : nullptr);
+    named_["model.15"] = {l15};
     conv(add_conv_weights(p, "model.16.conv", 0), l15, slice(cat17, 0, ch[2]), 2, 1);
     View l18 = c2f(p, "model.18", cat17, nh, false, nullptr);
+    named_["model.18"] = {l18};
     conv(add_conv_weights(p, "model.19.conv", 0), l18, slice(cat20, 0, ch[3]), 2, 1);
     View l21 = c2f(p, "model.21", cat20, nh, false, nullptr);
+    named_["model.21"] = {l21};
 
     // Detect
     const View feats[3] = {l15, l18, l21};
@@ -802,6 +816,24 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
                                op.head_stride, op.a_off, anchors_);
             break;
     }
+}
+
+bool Yolov8::read_feature(hipStream_t s, const std::string& name, int img, float* out, int dims[3]) {
+    const auto it = named_.find(name);
+    if (it == named_.end()) return false;
+    const View& v = it->second.v;
+    dims[0] = v.h, dims[1] = v.w, dims[2] = v.c;
+    if (!out) return true;
+    if (img < 0 || img >= chunk_) fail(RMR_ERR_INVALID_ARGUMENT, "read_feature: image %d is outside the last chunk", img);
+    // stage outputs are interleaved NHWC views (pixel pitch cs, first channel co)
+    const size_t px = (size_t)v.h * v.w;
+    std::vector<__half> host(px * v.cs);
+    RMR_HIP(hipMemcpyAsync(host.data(), arena_.p + v.off * chunk_ + (size_t)img * px * v.cs, host.size() * sizeof(__half),
+                           hipMemcpyDeviceToHost, s));
+    RMR_HIP(hipStreamSynchronize(s));
+    for (size_t p = 0; p < px; ++p)
+        for (int c = 0; c < v.c; ++c) out[p * v.c + c] = __half2float(host[p * v.cs + v.co + c]);
+    return true;
 }
 
 Yolov8::~Yolov8() {

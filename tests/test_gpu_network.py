@@ -322,3 +322,58 @@ def test_interleaved_chunks_plan_still_matches(rmr, packs, refs, images, oracle,
     det.close()
     blobs = np.stack([oracle.preprocess(im)[0] for im in images])
     _check_head(got, refs["armor"][1].forward(blobs), 2.0, 1e-2)
+
+
+# Mean |HIP - f16-emulating oracle| per stage output (image 1 and 2 of the fixture, car pack), measured with
+# tools/stage_errors.py and given ~2.5x room.  The stages are bit-exact or one f16 ulp apart at the first two
+# layers and drift by ~6e-4 of the activations' rms (1.3-1.6) through 80 convolutions: this is where the
+# 2 px bound on the decoded boxes comes from -- a DFL distance is a softmax expectation over 16 bins of logits
+# built from these features, times a stride of up to 32 px.
+STAGE_BUDGET = {"model.0": 2e-5, "model.1": 2e-5, "model.2": 4e-4, "model.3": 6e-4, "model.4": 1.0e-3,
+                "model.5": 1.2e-3, "model.6": 1.3e-3, "model.7": 1.4e-3, "model.8": 1.5e-3, "model.9": 1.6e-3,
+                "model.12": 1.7e-3, "model.15": 1.9e-3, "model.18": 2.2e-3, "model.21": 2.0e-3}
+
+
+def test_stage_error_budget(rmr, packs, images):
+    """Every backbone / neck stage output against the f16-emulating oracle: the error budget layer by layer
+    (the head tolerance of the other tests is the end of this table, not an assumption)."""
+    import oracle
+    from oracle import yolov8_ref as R
+    det = rmr.Detector(packs[0], 1, (1920, 1080), 2)
+    det.infer(images[:2])
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images[:2]])
+    want = R.load(packs[0], True).features(blobs)
+    assert set(want) == set(STAGE_BUDGET)
+    for name, budget in STAGE_BUDGET.items():
+        for img in range(2):
+            got = det.read_feature(name, img)
+            w = want[name][img]
+            assert got.shape == w.shape
+            err = np.abs(got - w)
+            # no value further than four f16 ulps at the activations' magnitude (|x| < 16: ulp 2^-7)
+            assert err.max() <= 4 * 2.0 ** -7, f"{name} image {img}: max error {err.max()}"
+            assert err.mean() <= budget, f"{name} image {img}: mean error {err.mean()} over the budget {budget}"
+    det.close()
+
+
+def test_pinned_plan_makes_an_image_independent_of_its_batch(rmr, packs, images, tmp_path, monkeypatch):
+    """RMR_PLAN: the kernel per layer comes from a plan file, nothing is timed.  With one kernel per layer
+    for every batch size (rm_radar_amd.pin_plan) an image's network output is BIT-identical alone, inside a
+    batch of three and at another position of the batch -- which the autotuned default cannot promise
+    (a batch of 1 and a batch of 3 may have been given different kernels)."""
+    same = [images[0], images[0], images[0]]
+    det = rmr.Detector(packs[1], 12, (1920, 1080), 3)      # tunes batch 3, writes <pack>.tune
+    det.infer(same)
+    det.close()
+    plan = rmr.pin_plan(packs[1] + ".tune", str(tmp_path / "armor.plan"), (1, 2, 3))
+    monkeypatch.setenv("RMR_PLAN", plan)
+    det = rmr.Detector(packs[1], 12, (1920, 1080), 3)
+    alone, _ = det.infer([images[0]])
+    three, _ = det.infer([images[1], images[0], images[2]])
+    pair, _ = det.infer([images[0], images[2]])
+    assert alone[0].tobytes() == three[1].tobytes() == pair[0].tobytes()
+    assert three[2].tobytes() == pair[1].tobytes()
+    # a plan that lacks a batch size fails loudly instead of timing kernels
+    with pytest.raises(rmr.RmrError):
+        rmr.Detector(packs[1], 12, (1920, 1080), 4).infer([images[0]] * 4)
+    det.close()
