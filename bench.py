@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled loop (no roofline objects)")
     ap.add_argument("--seconds", type=float, default=10.0, help="steady state: keep stepping until this much time is measured")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--gather", choices=("abi", "torch"), default="abi",
+                    help="N > 1: the robot-record all-gather through the library's C-ABI communicator (rmr_comm_*, RCCL) "
+                         "or through torch.distributed (RCCL as well)")
     ap.add_argument("--config", type=int, default=2, help="BASELINE configs index: 2 = 640x640 + 30k points; 3 = one 1920x1080 "
                     "stream + 100k-point clouds per GPU")
     args = ap.parse_args()
@@ -213,15 +216,37 @@ def main():
     frames = rmr.FrameBatch(img_list, cloud_list)
     forced = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(B, -1, 4))
 
+    # The exchange of the path: by default through the C-ABI a C++ host would use (include/rmr.h, rmr_comm_*:
+    # ncclAllGather on this rank's GPU); the 128-byte id travels over the torch.distributed group that exists
+    # anyway for the barrier and the max-over-ranks clock.  A failure to set it up falls back to torch.distributed.
+    comm, gather_via = None, "none (one rank, no process group)"
+    if use_dist:
+        gather_via = "torch.distributed all_gather_into_tensor (RCCL)"
+        if args.gather == "abi":
+            try:
+                ids = [rd.Comm.unique_id("rccl") if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                comm = rd.Comm("rccl", rank, world, ids[0], device=local)
+                probe = comm.all_gather_records(np.full((1, 1, rd.RECORD_WORDS), rank + 1, np.int32))
+                assert probe.shape[0] == world and all(int(probe[r, 0, 0, 0]) == r + 1 for r in range(world))
+                gather_via = "rmr_comm_all_gather_records (C-ABI, RCCL ncclAllGather)"
+            except Exception as e:  # noqa: BLE001
+                comm = None
+                gather_via += f" [C-ABI communicator unavailable: {type(e).__name__}: {e}]"
+
     def step():
         # one native call in the reference's order (sample_radar.h:106-127): update + cluster of
         # the 64 frames on a helper thread while detect runs, join, then one batched search
         t0 = time.perf_counter()
         robots, counts = rmr.run_batch(rdet, loc, frames, None, forced)
         t3 = time.perf_counter()
-        block = torch.from_numpy(rd.pack_records(robots, counts, cap, rank, cap))
-        if use_dist:
-            block = rd.all_gather_records(block.to(dev), force=True)
+        block = rd.pack_records(robots, counts, cap, rank, cap)
+        if comm is not None:
+            block = torch.from_numpy(comm.all_gather_records(block))
+        elif use_dist:
+            block = rd.all_gather_records(torch.from_numpy(block).to(dev), force=True)
+        else:
+            block = torch.from_numpy(block)
         t4 = time.perf_counter()
         phases["detect_locate_search"] += t3 - t0
         phases["pack_gather"] += t4 - t3
@@ -366,6 +391,7 @@ def main():
             "value_incl_h2d": None if h2d_ms is None else round(B * world / (dt / args.steps + h2d_ms * 1e-3), 2),
             "end_to_end_tflops": round(flops_frame * frames / dt / 1e12, 2),
             "host_phase_ms_per_step": {k: round(v / args.steps * 1e3, 2) for k, v in headline_phases.items()},
+            "gather": gather_via,
             "located_last_step": n_located,
         }
 

@@ -90,10 +90,38 @@ typedef struct {
     float location[3];
     float confidence;
     int32_t label;      /* -1 when not detected */
-    int32_t flags;      /* bit0 has_label, bit1 has_location */
+    int32_t flags;      /* bit0 has_label, bit1 has_location, bit2 slot filled */
     int32_t stream_id;
     int32_t frame_id;
 } rmr_robot_record;
+
+/* ---------------------------------------------------------------- multi-GPU (one process per GPU)
+ * No reference counterpart: the reference pins device 0 (detector.cpp:61) and runs one camera / LiDAR stream
+ * (samples/sample_radar.h:106-127).  Streams shard over ranks (a stream's Locator state never migrates); the
+ * only exchange of the path is one all-gather of the final robot list per batch of frames. */
+
+typedef struct rmr_comm rmr_comm;
+enum {
+    RMR_TRANSPORT_RCCL = 0, /* ncclAllGather over xGMI; librccl.so is opened on first use            */
+    RMR_TRANSPORT_FILE = 1  /* a shared directory (the id is its path): hosts / CI without GPUs      */
+};
+#define RMR_COMM_ID_BYTES 128
+
+/* rank that owns stream s: s % world */
+int rmr_stream_owner(int stream, int world);
+/* the streams of `rank` in ascending order into out[cap]; returns their number */
+int rmr_streams_of_rank(int n_streams, int rank, int world, int* out, int cap);
+/* rank 0 creates the id; the host application hands it to the other ranks (env, file, MPI, socket ...) */
+rmr_status rmr_comm_unique_id(int transport, char* id /* [RMR_COMM_ID_BYTES] */);
+/* collective over all ranks (RCCL: ncclCommInitRank on `device`) */
+rmr_status rmr_comm_create(int transport, int device, int rank, int world, const char* id, rmr_comm** out);
+void rmr_comm_destroy(rmr_comm* comm);
+/* every rank contributes n records (the same n on every rank); all[world][n] on every rank on return */
+rmr_status rmr_comm_all_gather_records(rmr_comm* comm, const rmr_robot_record* mine, int n, rmr_robot_record* all);
+/* robots[n_frames][cap] + counts[n_frames] -> out[n_frames][max_per_frame], zero padded; flags bit 2 marks a
+ * filled slot */
+rmr_status rmr_pack_robot_records(const rmr_robot* robots, const int* counts, int n_frames, int cap, int stream_id,
+                                  int max_per_frame, rmr_robot_record* out);
 
 /* ---------------------------------------------------------------- geometry (host) */
 

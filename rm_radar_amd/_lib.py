@@ -131,6 +131,13 @@ SYMBOLS = {
     "rmr_conv2d": (C.c_int, [C.c_int, _fp] + [C.c_int] * 4 + [_fp, _fp] + [C.c_int] * 6 +
                    [_fp, _fp, C.c_int]),
     "rmr_conv_bench": (C.c_int, [C.c_int] * 11 + [_fp]),
+    "rmr_stream_owner": (C.c_int, [C.c_int, C.c_int]),
+    "rmr_streams_of_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, C.c_int]),
+    "rmr_comm_unique_id": (C.c_int, [C.c_int, C.c_char_p]),
+    "rmr_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _P(_vp)]),
+    "rmr_comm_destroy": (None, [_vp]),
+    "rmr_comm_all_gather_records": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "rmr_pack_robot_records": (C.c_int, [_vp, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rmr_detector_cfg_default": (None, [_P(DetectorCfg)]),
     "rmr_detector_create": (C.c_int, [_P(DetectorCfg), _P(_vp)]),
     "rmr_detector_destroy": (None, [_vp]),

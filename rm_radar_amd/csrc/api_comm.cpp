@@ -1,0 +1,222 @@
+// api_comm.cpp -- the multi-GPU part of the drop-in boundary: which rank owns a camera / LiDAR stream, and the
+// ONE exchange of the path -- an all-gather of the final robot list as fixed-size records, once per batch of
+// frames.  No reference counterpart: the reference pins device 0 (src/detect/detector.cpp:61) and
+// has a single stream (samples/sample_radar.h:106-127).  One process per GPU; the host application hands the
+// 128-byte id that rank 0 creates to the other ranks by whatever it has (environment, file, MPI, a socket).
+//
+// Transports:
+//   RMR_TRANSPORT_RCCL  ncclAllGather over xGMI on the rank's GPU.  librccl.so is opened at the first
+//                       communicator, so hosts that never go multi-GPU do not load it.
+//   RMR_TRANSPORT_FILE  the same exchange through a shared directory (the id is its path): for hosts and CI
+//                       boxes without GPUs, and for testing a C++ caller with several processes on one box.
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "common.h"
+
+using namespace rmr;
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    });
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
+        fail(RMR_ERR_DEVICE, "librccl.so cannot be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    return r;
+}
+
+void nccl_check(ncclResult_t e, const char* what) {
+    if (e != ncclSuccess) fail(RMR_ERR_DEVICE, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(e) : "RCCL error");
+}
+
+}  // namespace
+
+struct rmr_comm {
+    int transport = 0, rank = 0, world = 1, device = 0;
+    // RCCL
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    DevBuf<unsigned char> send, recv;
+    // FILE
+    std::string dir;
+    long long seq = 0;
+    ~rmr_comm() {
+        if (comm) (void)rccl().CommDestroy(comm);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" {
+
+int rmr_stream_owner(int stream, int world) { return world > 0 && stream >= 0 ? stream % world : -1; }
+
+int rmr_streams_of_rank(int n_streams, int rank, int world, int* out, int cap) {
+    int n = 0;
+    for (int s = 0; s < n_streams; ++s)
+        if (rmr_stream_owner(s, world) == rank) {
+            if (out && n < cap) out[n] = s;
+            ++n;
+        }
+    return n;
+}
+
+rmr_status rmr_comm_unique_id(int transport, char* id) {
+    return guarded([&] {
+        if (!id) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_unique_id: null id");
+        std::memset(id, 0, RMR_COMM_ID_BYTES);
+        if (transport == RMR_TRANSPORT_RCCL) {
+            static_assert(sizeof(ncclUniqueId) == RMR_COMM_ID_BYTES, "the id is an ncclUniqueId");
+            ncclUniqueId u;
+            nccl_check(rccl().GetUniqueId(&u), "ncclGetUniqueId");
+            std::memcpy(id, &u, sizeof(u));
+        } else if (transport == RMR_TRANSPORT_FILE) {
+            const char* base = std::getenv("TMPDIR");
+            std::string tmpl = std::string(base && *base ? base : "/tmp") + "/rmr_comm_XXXXXX";
+            if (tmpl.size() >= RMR_COMM_ID_BYTES) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_unique_id: TMPDIR is too long");
+            std::vector<char> buf(tmpl.begin(), tmpl.end());
+            buf.push_back(0);
+            if (!mkdtemp(buf.data())) fail(RMR_ERR_RUNTIME, "rmr_comm_unique_id: cannot create a directory under %s", tmpl.c_str());
+            std::memcpy(id, buf.data(), buf.size());
+        } else {
+            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_unique_id: unknown transport %d", transport);
+        }
+    });
+}
+
+rmr_status rmr_comm_create(int transport, int device, int rank, int world, const char* id, rmr_comm** out) {
+    return guarded([&] {
+        if (!out || !id || world < 1 || rank < 0 || rank >= world) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: bad arguments");
+        auto c = std::make_unique<rmr_comm>();
+        c->transport = transport, c->rank = rank, c->world = world, c->device = device;
+        if (transport == RMR_TRANSPORT_RCCL) {
+            DeviceCtx& ctx = device_ctx(device);  // fails loudly without a usable GPU
+            ctx.use();
+            ncclUniqueId u;
+            std::memcpy(&u, id, sizeof(u));
+            RMR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            nccl_check(rccl().CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");
+        } else if (transport == RMR_TRANSPORT_FILE) {
+            c->dir.assign(id, strnlen(id, RMR_COMM_ID_BYTES));
+            struct stat st;
+            if (c->dir.empty() || stat(c->dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: '%s' is not a directory", c->dir.c_str());
+        } else {
+            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: unknown transport %d", transport);
+        }
+        *out = c.release();
+    });
+}
+
+void rmr_comm_destroy(rmr_comm* c) { delete c; }
+
+rmr_status rmr_comm_all_gather_records(rmr_comm* c, const rmr_robot_record* mine, int n, rmr_robot_record* all) {
+    return guarded([&] {
+        if (!c || !mine || !all || n <= 0) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_all_gather_records: bad arguments");
+        const size_t bytes = (size_t)n * sizeof(rmr_robot_record);
+        if (c->world == 1 && c->transport == RMR_TRANSPORT_FILE) {
+            std::memcpy(all, mine, bytes);
+            return;
+        }
+        if (c->transport == RMR_TRANSPORT_RCCL) {
+            // a few KB per rank: latency-bound, so one call per batch of frames.  Host records are staged through
+            // device buffers because the collective moves device memory.
+            RMR_HIP(hipSetDevice(c->device));
+            c->send.ensure(bytes);
+            c->recv.ensure(bytes * c->world);
+            RMR_HIP(hipMemcpyAsync(c->send.p, mine, bytes, hipMemcpyHostToDevice, c->stream));
+            nccl_check(rccl().AllGather(c->send.p, c->recv.p, bytes, ncclChar, c->comm, c->stream), "ncclAllGather");
+            RMR_HIP(hipMemcpyAsync(all, c->recv.p, bytes * c->world, hipMemcpyDeviceToHost, c->stream));
+            RMR_HIP(hipStreamSynchronize(c->stream));
+            return;
+        }
+        // FILE: publish <seq>.<rank> (written under another name, then renamed: readers never see a partial file),
+        // collect everybody's, retire the files of two rounds ago (every rank has read them by then)
+        const long long seq = c->seq++;
+        const auto name = [&](long long s, int r) { return c->dir + "/" + std::to_string(s) + "." + std::to_string(r); };
+        {
+            const std::string tmp = name(seq, c->rank) + ".tmp";
+            std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+            f.write((const char*)mine, (std::streamsize)bytes);
+            f.close();
+            if (!f || std::rename(tmp.c_str(), name(seq, c->rank).c_str()) != 0)
+                fail(RMR_ERR_RUNTIME, "rmr_comm_all_gather_records: cannot publish into '%s'", c->dir.c_str());
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < c->world; ++r) {
+            for (;;) {
+                std::ifstream f(name(seq, r), std::ios::binary);
+                if (f) {
+                    f.read((char*)all + (size_t)r * bytes, (std::streamsize)bytes);
+                    if ((size_t)f.gcount() == bytes) break;
+                    fail(RMR_ERR_RUNTIME, "rmr_comm_all_gather_records: rank %d published %zu bytes, expected %zu (ranks disagree on n)", r,
+                         (size_t)f.gcount(), bytes);
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                    fail(RMR_ERR_RUNTIME, "rmr_comm_all_gather_records: rank %d did not arrive within 120 s", r);
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        }
+        if (seq >= 2) std::remove(name(seq - 2, c->rank).c_str());
+    });
+}
+
+// rmr_robot[n_frames * cap] + counts -> records [n_frames][max_per_frame], zero padded; a slot is valid when
+// flags bit 2 is set (bit 0: label, bit 1: location)
+rmr_status rmr_pack_robot_records(const rmr_robot* robots, const int* counts, int n_frames, int cap, int stream_id,
+                                  int max_per_frame, rmr_robot_record* out) {
+    return guarded([&] {
+        if (!robots || !counts || !out || n_frames <= 0 || cap <= 0 || max_per_frame <= 0)
+            fail(RMR_ERR_INVALID_ARGUMENT, "rmr_pack_robot_records: bad arguments");
+        std::memset(out, 0, (size_t)n_frames * max_per_frame * sizeof(rmr_robot_record));
+        for (int f = 0; f < n_frames; ++f) {
+            const int m = std::min(std::min(counts[f], cap), max_per_frame);
+            for (int i = 0; i < m; ++i) {
+                const rmr_robot& r = robots[(size_t)f * cap + i];
+                rmr_robot_record& o = out[(size_t)f * max_per_frame + i];
+                std::memcpy(o.rect, r.rect, sizeof(o.rect));
+                std::memcpy(o.location, r.location, sizeof(o.location));
+                o.confidence = r.confidence;
+                o.label = r.has_label ? r.label : -1;
+                o.flags = (r.has_label ? 1 : 0) | (r.has_location ? 2 : 0) | 4;
+                o.stream_id = stream_id;
+                o.frame_id = f;
+            }
+        }
+    });
+}
+
+}  // extern "C"

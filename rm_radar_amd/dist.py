@@ -88,3 +88,50 @@ def all_gather_records(block, group=None, force=False):
                       device=block.device)
     dist.all_gather_into_tensor(out, block, group=group)
     return out.view((world,) + tuple(block.shape))
+
+
+class Comm:
+    """The C-ABI communicator (include/rmr.h: rmr_comm_*): what a C++ host would use, mirrored for Python hosts.
+    transport: "rccl" (ncclAllGather over xGMI on `device`) or "file" (a shared directory; no GPU needed).
+    `unique_id()` on rank 0, the 128 bytes to every rank by any channel, then `Comm(...)` on all ranks."""
+    TRANSPORTS = {"rccl": 0, "file": 1}
+
+    @staticmethod
+    def unique_id(transport="rccl") -> bytes:
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().rmr_comm_unique_id(Comm.TRANSPORTS[transport], buf))
+        return buf.raw
+
+    def __init__(self, transport, rank, world, uid: bytes, device=0):
+        self.rank, self.world = rank, world
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().rmr_comm_create(Comm.TRANSPORTS[transport], device, rank, world,
+                                              C.create_string_buffer(uid, 128), C.byref(self._h)))
+
+    def all_gather_records(self, block: np.ndarray) -> np.ndarray:
+        """block: int32 [..., 12] records of this rank -> [world, ..., 12] on every rank."""
+        block = np.ascontiguousarray(block, np.int32)
+        n = block.size // RECORD_WORDS
+        out = np.empty((self.world,) + block.shape, np.int32)
+        _lib.check(_lib.lib().rmr_comm_all_gather_records(self._h, block.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().rmr_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_records_abi(robots_c, counts, cap: int, stream_id: int, max_per_frame: int) -> np.ndarray:
+    """pack_records through the C-ABI (rmr_pack_robot_records): the same [n_frames, max_per_frame, 12] block."""
+    counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros((len(counts), max_per_frame, RECORD_WORDS), np.int32)
+    _lib.check(_lib.lib().rmr_pack_robot_records(C.addressof(robots_c), _lib.ip(counts), len(counts), cap, stream_id,
+                                                 max_per_frame, out.ctypes.data))
+    return out

@@ -90,3 +90,70 @@ def test_single_process_gather_is_identity():
     from rm_radar_amd import dist as rd
     x = torch.arange(24, dtype=torch.int32).reshape(1, 2, 12)
     assert torch.equal(rd.all_gather_records(x)[0], x)
+
+
+def _build_gather_exe():
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    libdir = os.path.join(ROOT, "rm_radar_amd", "_build")
+    exe = os.path.join(libdir, "gather_ranks")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "gather_ranks.cpp"), "-L", libdir, "-lrmr",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_cpp_hosts_gather_through_the_c_abi_world2(tmp_path):
+    """Two C++ processes (tests/cpp/gather_ranks.cpp) drive the multi-GPU boundary -- stream assignment,
+    rmr_pack_robot_records, rmr_comm_all_gather_records -- over the file transport (no GPU on this box; on a
+    node with GPUs the same program runs with transport 0 = RCCL).  Both ranks must print the same table: the
+    robots of all five streams, for three rounds."""
+    import subprocess
+    exe = _build_gather_exe()
+    idf = str(tmp_path / "comm.id")
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    procs = [subprocess.Popen([exe, "1", idf, str(r), "2", "5", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    tables = [[l for l in so.splitlines() if l.startswith("round")] for so, _ in outs]
+    assert tables[0] == tables[1]
+    # streams 0, 2, 4 live on rank 0 and 1, 3 on rank 1; 3 robots per stream per round
+    assert len(tables[0]) == 3 * 5 * 3
+    streams = sorted({int(l.split()[3]) for l in tables[0]})
+    assert streams == [0, 1, 2, 3, 4]
+    assert any("stream 3 frame 1 rect 301 0 12 20 label 6 loc 4 3 3" in l for l in tables[0])
+
+
+def test_python_comm_mirror_matches_numpy_packing(tmp_path):
+    """rm_radar_amd.dist.Comm over the file transport with one rank, and rmr_pack_robot_records against the
+    numpy packer."""
+    sys.path.insert(0, ROOT)
+    from rm_radar_amd import _lib, dist as rd
+    os.environ["TMPDIR"] = str(tmp_path)
+    n_frames, cap = 3, 4
+    robots = (_lib.Robot * (n_frames * cap))()
+    counts = np.array([2, 0, 4], np.int32)
+    for f in range(n_frames):
+        for i in range(counts[f]):
+            r = robots[f * cap + i]
+            r.rect[:] = [f, i, 10 + f, 20 + i]
+            r.has_label = int(i % 2 == 0)
+            r.label = 3 + i
+            r.confidence = 0.5 + 0.1 * i
+            r.has_location = int(i % 2 == 1)
+            r.location[:] = [1.0, 2.0 + f, 3.0 + i]
+    a = rd.pack_records(robots, counts, cap, 7, cap)
+    b = rd.pack_records_abi(robots, counts, cap, 7, cap)
+    valid = (a[..., 9] & 4) != 0
+    assert np.array_equal(valid, (b[..., 9] & 4) != 0)
+    for w in (0, 1, 2, 3, 8, 9, 10, 11):   # rect, label, flags, stream, frame of the filled slots
+        assert np.array_equal(a[..., w][valid], b[..., w][valid])
+    lab, locd = (a[..., 9] & 1) != 0, (a[..., 9] & 2) != 0
+    assert np.array_equal(a[..., 7][lab], b[..., 7][lab]) and np.array_equal(a[..., 4:7][locd], b[..., 4:7][locd])
+    comm = rd.Comm("file", 0, 1, rd.Comm.unique_id("file"))
+    assert np.array_equal(comm.all_gather_records(b)[0], b)
+    comm.close()
+    assert _lib.lib().rmr_stream_owner(5, 4) == 1

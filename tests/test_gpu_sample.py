@@ -16,20 +16,37 @@ torch = pytest.importorskip("torch")
 
 
 def test_sample_radar_run_once_matches_oracle(tmp_path_factory, oracle):
+    size = scenes.SAMPLE_SIZE
+    frames = [netutil.test_image(40 + i, *size) for i in range(2)]
+    _run_once_case(tmp_path_factory, oracle, frames, size, scenes.SAMPLE_K)
+
+
+def test_sample_radar_on_the_reference_sample_frames(tmp_path_factory, oracle):
+    """BASELINE configs[1]: the reference's own sample frames (assets/images/0..9.jpg, committed 4x down-scaled
+    as tests/golden/assets_images by make_assets_images.py; samples/main.cpp:24-72 reads them with cv::imread)
+    with its sample clouds, batch 1, the sample's calibration scaled with the frames."""
+    from rm_radar_amd import assets
+    gold = os.path.join(os.path.dirname(__file__), "golden", "assets_images")
+    frames = [assets.read_image(os.path.join(gold, f"{i}.jpg")) for i in range(3)]
+    assert frames[0].shape == (512, 648, 3) and frames[0].dtype == np.uint8
+    K = scenes.SAMPLE_K.copy()
+    K[:2] *= 0.25
+    _run_once_case(tmp_path_factory, oracle, frames, (648, 512), K, min_box=12)
+
+
+def _run_once_case(tmp_path_factory, oracle, frames, size, K_cam, min_box=40):
     import rm_radar_amd as rmr
     from oracle import yolov8_ref as R
     from rm_radar_amd.sample import SampleRadar
-    size = scenes.SAMPLE_SIZE
-    frames = [netutil.test_image(40 + i, *size) for i in range(2)]
     d = tmp_path_factory.mktemp("sample_packs")
     car = netutil.tuned_pack(str(d / "car.rmrw"), 1, 21, 0.25, 0.002, frames[:1])
     armor = netutil.tuned_pack(str(d / "armor.rmrw"), 12, 22, 0.50, 0.01, [netutil.test_image(1)])
     data = np.load(os.path.join(os.path.dirname(__file__), "golden", "assets_clouds.npz"))
     rng = np.random.default_rng(9)
-    background = scenes.make_cloud(rng, 60000, scenes.SAMPLE_K, scenes.SAMPLE_L2C, size)
+    background = scenes.make_cloud(rng, 60000, K_cam, scenes.SAMPLE_L2C, size)
 
-    radar = SampleRadar(car, armor, size, scenes.SAMPLE_K, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C)
-    cpu_loc = oracle.Locator(size[0], size[1], scenes.SAMPLE_K, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C)
+    radar = SampleRadar(car, armor, size, K_cam, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C)
+    cpu_loc = oracle.Locator(size[0], size[1], K_cam, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C)
     car_ref, armor_ref = R.load(car), R.load(armor)
     radar.update_background_cloud(background)
     cpu_loc.update(background)
@@ -42,8 +59,8 @@ def test_sample_radar_run_once_matches_oracle(tmp_path_factory, oracle):
         blob, p = oracle.preprocess(img)
         cars = oracle.postprocess(car_ref.forward(blob[None])[0], 1, 0.65, 0.25, p)[:20]
         robots_spec = [((float(c["x"]), float(c["y"]), float(c["width"]), float(c["height"])), 2000.0, 300)
-                       for c in cars if c["width"] > 40 and c["height"] > 40][:4]
-        extra = scenes.make_cloud(rng, 20000, scenes.SAMPLE_K, scenes.SAMPLE_L2C, size, robots_spec,
+                       for c in cars if c["width"] > min_box and c["height"] > min_box][:4]
+        extra = scenes.make_cloud(rng, 20000, K_cam, scenes.SAMPLE_L2C, size, robots_spec,
                                   zero_frac=0, far_frac=0)
         asset = np.zeros((10000, 4), np.float32)
         asset[:, :3] = data[f"cloud{f}"]
@@ -162,3 +179,16 @@ def test_headless_cli_runs_the_reference_sample_layout(tmp_path, capsys):
     assert out[0].startswith("frame 0: ") and any(l.startswith("frame 1: ") for l in out)
     with pytest.raises(FileNotFoundError):
         sample.main(["--models", str(models), "--assets", str(ad), "--frames", "3"])  # main.cpp:33-35: missing frame
+
+
+def test_rccl_communicator_through_the_c_abi_one_rank():
+    """rmr_comm_* with the RCCL transport on the GPU of this box (a single rank: ncclCommInitRank + ncclAllGather
+    through librccl.so as a multi-GPU host would call them; world > 1 needs more GPUs than the test box has --
+    the file transport covers world = 2 in tests/test_dist_gloo.py)."""
+    from rm_radar_amd import dist as rd
+    comm = rd.Comm("rccl", 0, 1, rd.Comm.unique_id("rccl"))
+    block = (np.arange(4 * 3 * rd.RECORD_WORDS, dtype=np.int32).reshape(4, 3, rd.RECORD_WORDS) * 7919) % 100003
+    for _ in range(3):
+        got = comm.all_gather_records(block)
+        assert got.shape == (1, 4, 3, rd.RECORD_WORDS) and np.array_equal(got[0], block)
+    comm.close()

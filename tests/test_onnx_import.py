@@ -1,5 +1,7 @@
-"""ONNX initialiser -> weight pack converter (rm_radar_amd/onnx_import.py): round trip through a
-hand-encoded ONNX protobuf (no onnx package in the image)."""
+"""ONNX initialiser -> weight pack converter (rm_radar_amd/onnx_import.py): round trips through a
+hand-encoded ONNX protobuf and through a file written by google.protobuf's own encoder from run-time
+declared onnx.proto3 messages (tests/onnx_writer.py; the onnx / torch.onnx writers are not usable in this
+image: both need the `onnx` package), and the imported pack through the Detector on the GPU."""
 import os
 import struct
 
@@ -100,3 +102,51 @@ def test_rejects_renamed_or_incomplete_graphs(tmp_path):
     (tmp_path / "c.onnx").write_bytes(b"\x08\x08")
     with pytest.raises(ValueError, match="no graph"):
         OI.onnx_to_pack(str(tmp_path / "c.onnx"), str(tmp_path / "c.rmrw"))
+
+
+def test_round_trip_through_protobuf_written_file(tmp_path):
+    """A second, independent writer: google.protobuf serialises the messages (packed repeated fields, its own
+    field order), initialisers alternate between raw f32, float_data and FLOAT16 raw, Conv nodes and int64
+    shape constants sit between them."""
+    import onnx_writer
+    t = W.synthesize("m", 12, seed=15)
+    path = onnx_writer.write_yolov8_onnx(str(tmp_path / "armor.onnx"), t)
+    assert OI.onnx_to_pack(path, str(tmp_path / "armor.rmrw")) == ("m", 12)
+    got, _ = W.load_pack(str(tmp_path / "armor.rmrw"))
+    assert list(got) == list(t)
+    for i, k in enumerate(t):
+        want = t[k].astype(np.float16).astype(np.float32) if i % 3 == 2 else t[k]
+        assert np.array_equal(got[k], want), k
+
+
+@pytest.mark.gpu
+def test_imported_onnx_runs_through_the_detector(tmp_path):
+    """detector.cpp:74-99 / 177-243: no engine on disk, an ONNX file next to it -> the engine is built from
+    the ONNX and the detector runs on it.  Here: armor.onnx written by the protobuf writer (raw f32 only),
+    Detector('armor.rmrw') builds the pack from it, and its network output equals -- bit for bit -- the
+    output on a pack saved directly from the same tensors, and the CPU oracle within the f16 tolerance."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import netutil
+    import onnx_writer
+    import oracle
+    import rm_radar_amd as rmr
+    from oracle import yolov8_ref as R
+    images = [netutil.test_image(1), netutil.test_image(2, 810, 1080)]
+    direct = netutil.tuned_pack(str(tmp_path / "direct.rmrw"), 12, 31, 0.5, 0.01, images)
+    tensors, _ = W.load_pack(direct)
+    onnx_writer.write_yolov8_onnx(str(tmp_path / "armor.onnx"), tensors, forms=("raw",))
+    assert not os.path.exists(tmp_path / "armor.rmrw")
+    det = rmr.Detector(str(tmp_path / "armor.rmrw"), 12, (1920, 1080), 2)   # builds the pack from armor.onnx
+    assert os.path.exists(tmp_path / "armor.rmrw")
+    got, _ = det.infer(images)
+    det.close()
+    # same kernels for both packs: the second detector runs the first one's plan
+    os.replace(str(tmp_path / "armor.rmrw.tune"), str(tmp_path / "direct.rmrw.tune"))
+    ref = rmr.Detector(direct, 12, (1920, 1080), 2)
+    want, _ = ref.infer(images)
+    ref.close()
+    assert got.tobytes() == want.tobytes()
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    cpu = R.load(str(tmp_path / "armor.rmrw"), True).forward(blobs)
+    assert np.abs(got[:, :4] - cpu[:, :4]).max() <= 2.0 and np.abs(got[:, 4:] - cpu[:, 4:]).max() <= 1e-2
