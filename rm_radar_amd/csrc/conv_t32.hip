@@ -80,7 +80,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // first tile of a workgroup pays a cold start, and the epilogue of a tile runs while the next tile's
 // operands are already in flight.
 template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles) {
+__global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 32;
     constexpr int BN = WN * NREP * 32;
@@ -163,6 +163,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
         s_wdst[j] = lds0 + ring_base + q * 1024;
         s_wsrc[j] = (unsigned)q * 1024u;
         s_aidx[j] = q - NB;
+    }
+
+    // Two workgroups share a CU so that one's epilogue (two transcendentals per output value: a third of the
+    // MFMA time of a K = 864 tile) runs under the other's K loop -- which only happens when they are out of
+    // phase.  Launched together and walking equal tiles they would stay in lockstep for the whole launch, so the
+    // workgroup in the CU's odd slot (HW_ID.TG_ID, the barrier resource it was given) starts half a tile late.
+    if (stagger > 0) {
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4);   // HW_REG_HW_ID[19:16] = TG_ID
+        if (hw_id & 1)
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles each
     }
 
     // ---- cold start: the whole input range of chunk 0, weight slices 0 .. R-2 of the first tile -----------
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
 
 struct T32Tile {
     int bm, bn, threads, a_slots, ring, nrep, epi, wgs_per_cu;
-    void (*kernel)(const ConvArgs, int, int);
+    void (*kernel)(const ConvArgs, int, int, int);
 };
 
 #define T32(WM, WN, MR, NR, AS, R, EPI, WPC) \
@@ -569,7 +579,11 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
         pname = names.emplace(buf, buf).first->second.c_str();
     }
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
-    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles);
+    // half a tile of head start for one workgroup of each CU pair: ~500 cycles per tap, in units of 4096 cycles
+    static const int stagger_env = std::getenv("RMR_T32_STAGGER") ? std::atoi(std::getenv("RMR_T32_STAGGER")) : -1;
+    const int taps = a.Cin / 32 * 9;
+    const int stagger = t.wgs_per_cu < 2 || grid <= ctx.num_cus ? 0 : stagger_env >= 0 ? stagger_env : (taps * 500 + 4095) / 4096;
+    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, stagger);
     RMR_HIP(hipGetLastError());
 }
 
