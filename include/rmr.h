@@ -171,11 +171,16 @@ rmr_status rmr_transpose(int device, const float* src, float* dst, int rows, int
  * w [cout][cin][kh][kw] (OIHW), bias [cout], residual/y [n][ho][wo][cout]. tile<0 = auto;
  * otherwise the kernel to test: 0..99 conv_igemm tile, 100..199 conv_dma tile (+ 1000 * split for
  * split-K), 200..299 conv_halo tile, 300..399 conv_ws variant, 400..499 conv_direct tile, 500 conv_stem,
- * 600..699 conv_ws_s2 variant, 700..799 conv_pw variant, 800..899 conv_t32 tile;
+ * 600..699 conv_ws_s2 variant, 700..799 conv_pw variant, 800..899 conv_t32 tile, 900..999 conv_t32f8 tile
+ * (e4m3 operands: the input is quantised on the device, the weights on the host);
  * RMR_ERR_INVALID_ARGUMENT if it cannot run the layer. */
 rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, const float* wt,
                       const float* bias, int cout, int kh, int kw, int stride, int pad, int silu,
                       const float* residual, float* y, int tile);
+
+/* Host side of the fp8 weight packer: OCP e4m3fn bytes of x[n], round to nearest even, saturating at 448
+ * (conv_t32f8.hip; the counterpart of choosing kFP16 / kINT8 at detector.cpp:208-231). */
+rmr_status rmr_f32_to_e4m3(const float* x, int n, unsigned char* out);
 
 /* Development hook: times one conv layer (bias + SiLU, f16 in / f16 out, optional residual) on
  * device-resident pseudo-random data with HIP events; kernel = a tiled family id as in rmr_conv2d

@@ -131,6 +131,7 @@ SYMBOLS = {
     "rmr_conv2d": (C.c_int, [C.c_int, _fp] + [C.c_int] * 4 + [_fp, _fp] + [C.c_int] * 6 +
                    [_fp, _fp, C.c_int]),
     "rmr_conv_bench": (C.c_int, [C.c_int] * 11 + [_fp]),
+    "rmr_f32_to_e4m3": (C.c_int, [_fp, C.c_int, _vp]),
     "rmr_stream_owner": (C.c_int, [C.c_int, C.c_int]),
     "rmr_streams_of_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, C.c_int]),
     "rmr_comm_unique_id": (C.c_int, [C.c_int, C.c_char_p]),

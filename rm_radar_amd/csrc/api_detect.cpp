@@ -179,6 +179,27 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             a.wt_t32 = dw32.p;
             a.wt_t32_bytes = (unsigned)(p32.size() * sizeof(__half));
         }
+        // conv_t32f8 (ids 900..): e4m3 weights with one scale per output channel, the input quantised on the device
+        DevBuf<unsigned char> dw8, dx8;
+        DevBuf<float> dws;
+        if (tile >= 900 && tile < 1000 && kh == 3 && kw == 3) {
+            std::vector<unsigned char> p8;
+            std::vector<float> ws;
+            pack_conv_weights_t32f8(packed.data(), cout_pad, cin_pad, a.Kp, p8, ws);
+            dw8.alloc(p8.size());
+            dws.alloc(ws.size());
+            RMR_HIP(hipMemcpy(dw8.p, p8.data(), p8.size(), hipMemcpyHostToDevice));
+            RMR_HIP(hipMemcpy(dws.p, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
+            const int pitch = (cin_pad + 63) / 64 * 64;
+            dx8.alloc(npx_in * pitch);
+            launch_quant_f8(ctx, ctx.stream, dx.p, cin_pad, 0, cin_pad, dx8.p, pitch, (long)npx_in);
+            a.in8 = dx8.p;
+            a.in8_cs = pitch;
+            a.in8_bytes = (unsigned)(npx_in * pitch);
+            a.wt8 = dw8.p;
+            a.wt8_bytes = (unsigned)p8.size();
+            a.wscale = dws.p;
+        }
         DevBuf<long long> dtiming;
         // per-phase cycle stamps of conv_dma / conv_direct: needs a build with -DRMR_CONV_TIMING_BUILD=1
         const bool want_timing = std::getenv("RMR_CONV_TIMING") != nullptr;
@@ -190,6 +211,11 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..799: conv_pw variant; 800..899: conv_t32 tile
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
+        } else if (tile >= 900 && tile < 1000) {
+            const int t = tile - 900;
+            if (t >= conv_t32f8_num_tiles() || !conv_t32f8_supported(a, t))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: fp8 tile %d cannot run this layer", t);
+            launch_conv_t32f8(ctx, ctx.stream, a, t);
         } else if (tile >= 800 && tile < 900) {
             const int t = tile - 800;
             if (t >= conv_t32_num_tiles() || !conv_t32_supported(a, t))
@@ -260,6 +286,14 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
     });
 }
 
+// Host e4m3 rounding of the weight packer (round to nearest even, OCP e4m3fn), for the CPU tests.
+rmr_status rmr_f32_to_e4m3(const float* x, int n, unsigned char* out) {
+    return guarded([&] {
+        if (!x || !out || n < 0) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_f32_to_e4m3: bad arguments");
+        for (int i = 0; i < n; ++i) out[i] = f32_to_e4m3(x[i]);
+    });
+}
+
 // One layer on device-resident f16 data, timed with HIP events: the kernel-development loop (tools/conv_bench.py).
 // x: random f16 NHWC (one image's worth replicated), f16 output, optional residual; `tile` as in rmr_conv2d
 // (only the tiled families: 0..299, 800..899).  ms_out = mean launch time over `reps` launches.
@@ -321,6 +355,26 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
             a.wt_t32 = dw32.p;
             a.wt_t32_bytes = (unsigned)(p32.size() * 2);
         }
+        DevBuf<unsigned char> dw8, dx8;
+        DevBuf<float> dws;
+        if (k == 3 && tile >= 900 && tile < 1000) {
+            std::vector<unsigned char> p8;
+            std::vector<float> ws;
+            pack_conv_weights_t32f8(hw.data(), cout, cin, a.Kp, p8, ws);
+            dw8.alloc(p8.size());
+            dws.alloc(ws.size());
+            RMR_HIP(hipMemcpy(dw8.p, p8.data(), p8.size(), hipMemcpyHostToDevice));
+            RMR_HIP(hipMemcpy(dws.p, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
+            const int pitch = (cin + 63) / 64 * 64;
+            dx8.alloc((size_t)n * h * w * pitch);
+            launch_quant_f8(ctx, ctx.stream, dx.p, cin, 0, cin, dx8.p, pitch, (long)n * h * w);
+            a.in8 = dx8.p;
+            a.in8_cs = pitch;
+            a.in8_bytes = (unsigned)((size_t)n * h * w * pitch);
+            a.wt8 = dw8.p;
+            a.wt8_bytes = (unsigned)p8.size();
+            a.wscale = dws.p;
+        }
         a.in = dx.p;
         a.in_cs = cin;
         a.N = n;
@@ -342,7 +396,11 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         a.in_bytes = (unsigned)(n * img_in * 2);
         a.wt_bytes = (unsigned)(hw.size() * 2);
         const auto launch = [&] {
-            if (tile >= 800 && tile < 900) {
+            if (tile >= 900 && tile < 1000) {
+                if (tile - 900 >= conv_t32f8_num_tiles() || !conv_t32f8_supported(a, tile - 900))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: fp8 tile %d cannot run this layer", tile - 900);
+                launch_conv_t32f8(ctx, ctx.stream, a, tile - 900);
+            } else if (tile >= 800 && tile < 900) {
                 if (tile - 800 >= conv_t32_num_tiles() || !conv_t32_supported(a, tile - 800))
                     fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: t32 tile %d cannot run this layer", tile - 800);
                 launch_conv_t32(ctx, ctx.stream, a, tile - 800);

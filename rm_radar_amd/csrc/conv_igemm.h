@@ -41,6 +41,14 @@ struct ConvArgs {
     // conv_t32 only: the same weights as the LDS images of their (chunk, tap) slices (pack_conv_weights_t32)
     const __half* wt_t32;
     unsigned wt_t32_bytes;
+    // conv_t32f8 only: the input quantised to e4m3 (rows of in8_cs bytes, zero beyond Cin), the weights as e4m3
+    // LDS images with one scale per output channel (pack_conv_weights_t32f8)
+    const unsigned char* in8;
+    int in8_cs;
+    unsigned in8_bytes;
+    const unsigned char* wt8;
+    unsigned wt8_bytes;
+    const float* wscale;
     // split-K (conv_dma only): `split` workgroups share one output tile, each accumulating a
     // contiguous range of K slices; partial tiles meet in splitk_ws and the last arriver (ticket in
     // splitk_cnt, which it resets to 0) reduces them and runs the epilogue.  split <= 1: off.
@@ -113,6 +121,15 @@ ConvTile conv_t32_tile(int id);
 bool conv_t32_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
 void pack_conv_weights_t32(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out);
+// the fp8 form (conv_t32f8.hip): e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4, f16 output
+int conv_t32f8_num_tiles();
+ConvTile conv_t32f8_tile(int id);
+bool conv_t32f8_supported(const ConvArgs& a, int tile);  // tile < 0: any
+void launch_conv_t32f8(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+void launch_quant_f8(DeviceCtx& ctx, hipStream_t stream, const __half* in, int cs, int co, int C, unsigned char* out, int pitch, long npix);
+void pack_conv_weights_t32f8(const __half* packed, int cout_pad, int cin, int Kp, std::vector<unsigned char>& out, std::vector<float>& scale);
+unsigned char f32_to_e4m3(float x);
+float e4m3_to_f32(unsigned char b);
 // picks the kernel family and tile for a layer (RMR_CONV=igemm|dma overrides) and launches it
 void launch_conv_auto(DeviceCtx& ctx, hipStream_t stream, const ConvArgs& a);
 

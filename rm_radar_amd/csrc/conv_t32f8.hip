@@ -1,31 +1,18 @@
-// conv_t32.hip -- 3x3 / stride 1 / pad 1 convolution on v_mfma_f32_32x32x16_f16, one 8-wave
-// workgroup per CU, written so that the K loop carries almost no scalar or vector-ALU work.
+// conv_t32f8.hip -- the fp8 form of conv_t32 (BASELINE configs[4]: fp8-MFMA weights, batch 256).
 //
-// conv_halo (round 1) stages the input range once per 32-channel chunk and takes the nine taps as
-// row shifts of the fragment reads; measured, its K loop is not short of bytes but of issue slots
-// and overlap: 7.6 VALU + 2.7 SALU per 16x16x32 MFMA, one barrier per 12-24 MFMAs with the fragment
-// reads AFTER it, 45 % of the wave time parked.  This kernel keeps the halo staging and changes
-// everything around it:
-//
-//   * 32x32x16 MFMAs (half the matrix instructions per FLOP, 32-cycle issue slots to hide the rest
-//     in), a wave tile of 64 pixels x 96..128 channels, 8 waves = 256 x 192 or 512 x 96 per CU so that
-//     the weight stream is shared by 256-512 pixels (one workgroup per CU, up to 256 VGPRs);
-//   * weights are re-packed on the host into the exact LDS image of a (chunk, tap) slice, swizzle
-//     included, so a weight DMA instruction reads ONE contiguous KiB (eight whole 128-byte lines)
-//     from a wave-uniform offset: lane * 16 in the VGPR, everything else in the scalar offset;
-//   * fragment reads run half a tap ahead of the MFMAs that consume them, ACROSS the barrier: a
-//     slice is waited for (counted vmcnt) one tap before its first read, so the reads of tap t + 1
-//     are legal before the barrier that opens tap t + 1, and the MFMAs behind a barrier start at once;
-//   * border taps are masked by redirecting the fragment read to a zero block, as before, but the
-//     nine validity bits of a lane live in SGPR pairs as lane masks (one v_cndmask per fragment and
-//     tap), and fragment i of a wave sits at a constant 2 KiB from fragment 0 (immediate offsets):
-//     the swizzle key has a period of 16 rows, so ONE address is computed per tap.
-//
-// LDS rows are 64 bytes (32 channels of one pixel / one output channel).  A lane of a 32x32x16
-// fragment read (row = lane & 31, k-half = lane >> 5) takes the 16-byte chunk (2 h + k-half) of its
-// row for the MFMA of K-step h; chunk c of row r is stored at slot c ^ ((r >> 2) & 3), which makes
-// every ds_read_b128 lane group cover all 64 banks once at every row shift.
+// Same persistent tile walker, halo staging, LDS-image weights and lane masks as conv_t32.hip; what changes:
+//   * operands are OCP e4m3: weights quantised on the host with one scale per output channel
+//     (pack_conv_weights_t32f8), activations with unit scale (a SiLU output lies in [-0.28, a few tens];
+//     e4m3 spans 2^-9 .. 448) by quant_f8_kernel below; the product is rescaled in the epilogue;
+//   * an LDS row is still 64 bytes, now 64 channels; a lane of a fragment read takes 32 of them (two
+//     ds_read_b128) and ONE v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales consumes them: twice the
+//     FLOPs per pipe cycle of the f16 form and -- measured, tools/microbench/mfma_fp8_power.hip -- 3.9 PFLOP/s
+//     at the power limit on random operands where f16 reaches 1.65;
+//   * a tap is one K-step, so the read-ahead is organised per fragment: the weight fragments are single
+//     buffered and re-read for the next tap as soon as their last MFMA of this tap has issued (MFMAs run
+//     weight-fragment-major), the pixel fragments are double buffered.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -39,6 +26,7 @@ namespace rmr {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -60,7 +48,6 @@ __device__ __forceinline__ void wait_vm() {
 template <int T>
 using tap_c = std::integral_constant<int, T>;
 
-// f(integral_constant<0>) ... f(integral_constant<N-1>): a loop whose index is a constant expression
 template <int K, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (K < N) {
@@ -70,7 +57,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // WM x WN waves, MREP x NREP fragments of 32 x 32 per wave, A_SLOTS input-range DMA instructions per
-// tap (the first 11 - R taps of a chunk carry the next chunk's range), R weight slices in the ring.
+// tap (the first 11 - R taps of a 64-channel chunk carry the next chunk's range), R weight slices in the ring.
 // EPI: 0 = results leave through v_permlane32_swap pairs as 16-byte stores (32 contiguous bytes per pixel),
 //      1 = through a per-wave LDS stage as whole rows (NREP * 64 contiguous bytes per pixel).
 //
@@ -79,8 +66,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // slices of the next one and its last chunk fetches the next tile's first input range, so only the very
 // first tile of a workgroup pays a cold start, and the epilogue of a tile runs while the next tile's
 // operands are already in flight.
-template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
+template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI, int WPC>
+__global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 32;
     constexpr int BN = WN * NREP * 32;
@@ -124,19 +111,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     const int W = a.W;
     const int npix = a.M;        // stride 1: input and output pixels share the linear index
 
-    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
-                           sgpr(a.in_bytes), sgpr(0x00020000u)};
-    const u32x4 wt_rsrc = {sgpr((unsigned)(size_t)a.wt_t32), sgpr((unsigned)((size_t)a.wt_t32 >> 32) & 0xffffu),
-                           sgpr(a.wt_t32_bytes), sgpr(0x00020000u)};
+    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in8), sgpr((unsigned)((size_t)a.in8 >> 32) & 0xffffu),
+                           sgpr(a.in8_bytes), sgpr(0x00020000u)};
+    const u32x4 wt_rsrc = {sgpr((unsigned)(size_t)a.wt8), sgpr((unsigned)((size_t)a.wt8 >> 32) & 0xffffu),
+                           sgpr(a.wt8_bytes), sgpr(0x00020000u)};
 
     // ---- DMA constants of this lane ----------------------------------------------------------
     const int lrow = lane >> 2;                                   // row inside a 16-row DMA block
     const int lch = (lane & 3) ^ ((lrow >> 2) & 3);               // logical 16-byte chunk it fetches
-    const unsigned cs2 = (unsigned)a.in_cs * 2u;
-    const unsigned in_cb = (unsigned)((a.in_co + lch * 8) * 2);
+    const unsigned cs2 = (unsigned)a.in8_cs;                      // bytes per pixel of the e4m3 activations
+    const unsigned in_cb = (unsigned)(lch * 16);
     const unsigned lane16 = (unsigned)lane * 16u;
     const int na = a_rows / 16;                                   // input-range DMA blocks per chunk
-    const int chunks = a.Cin / 32;
+    const int chunks = (a.Cin + 63) / 64;   // a partial last chunk is zero padded in both operands
     const int total = chunks * 9;
     const unsigned wstep = (unsigned)(a.Cout_pad / 16) * 1024u;   // bytes of one (chunk, tap) slice of all channels
     const unsigned scratch = sgpr(lds0 + zero_off);
@@ -192,12 +179,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     int zsel[MREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i) zsel[i] = zero_off - i * 2048;
-    const int wlane = ring_base + (wn * NREP * 32 + fr) * 64 + ((kq ^ ((fr >> 2) & 3)) << 4);
-    const auto lds16 = [&](int off) { return *(const half8*)(smem + off); };
-    // address of fragment 0's chunk for K-step 0 of tap t, in input buffer `abuf`
+    const int wlane = ring_base + (wn * NREP * 32 + fr) * 64 + (((2 * kq) ^ ((fr >> 2) & 3)) << 4);
+    // a lane's 32 channels of a row: the 16-byte chunks 2 kq and 2 kq + 1 (slots c ^ key: 16 bytes apart)
+    const auto lds32 = [&](int off) {
+        typedef int intx4 __attribute__((ext_vector_type(4)));
+        const intx4 lo4 = *(const intx4*)(smem + off);
+        const intx4 hi4 = *(const intx4*)(smem + (off ^ 16));
+        return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // address of fragment 0's first chunk for tap t, in input buffer `abuf`
     const auto a_addr = [&](int abuf, int t) {
         const int row = a_row0 + (t / 3 - 1) * W + (t % 3 - 1);
-        return abuf + row * 64 + ((kq ^ ((row >> 2) & 3)) << 4);
+        return abuf + row * 64 + (((2 * kq) ^ ((row >> 2) & 3)) << 4);
     };
 
     wait_vm<0>();
@@ -241,20 +234,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // fragments of (tap 0, K-step 0): the slice and the range were waited for before the last barrier
-        half8 xa[MREP], wa[NREP], xb[MREP], wb[NREP];
-        int selx[MREP];
+        // fragments of tap 0: the slice and the range were waited for before the last barrier
+        intx8 X[MREP], Xn[MREP], Wf[NREP];   // pixel fragments of this tap and of the next one; weight fragments (rolling)
         int wcur = wlane + slot * SLOT_BYTES;
         {
             const int at = a_addr(abuf, 0);
 #pragma unroll
-            for (int i = 0; i < MREP; ++i) {
-                selx[i] = (up[i] && lf[i]) ? at : zsel[i];
-                xa[i] = lds16(selx[i] + i * 2048);
-            }
+            for (int i = 0; i < MREP; ++i) X[i] = lds32(((up[i] && lf[i]) ? at : zsel[i]) + i * 2048);
 #pragma unroll
-            for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
+            for (int j = 0; j < NREP; ++j) Wf[j] = lds32(wcur + j * 2048);
         }
+        int at_n = a_addr(abuf, 1);   // where the next tap's pixel fragments are (computed one tap ahead)
 
         for (int cc = 0; cc < chunks; ++cc) {
             const int abuf_next = a_buf_bytes - abuf;
@@ -263,94 +253,66 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
             const bool a_live = in_tile || has_next;
             const int a_pl = in_tile ? pl : pln;
             const int a_cc = in_tile ? cc + 1 : 0;
-            // One tap = 2 NM MFMAs (K-step 0, then K-step 1); everything else is placed by hand into the gaps
-            // behind them (a 32x32x16 MFMA occupies the pipe for 32 cycles).  The fragments of a K-step are read
-            // one K-step ahead: those of the next tap's K-step 0 BEFORE the barrier that opens that tap, so the
-            // first MFMAs behind a barrier never wait for the LDS.
+            // One tap = NM MFMAs of 64 pipe cycles, weight-fragment-major: fragment j serves MFMAs j MREP .. and is
+            // re-read for the next tap behind its last one; the next tap's pixel fragments and the DMA issue ride
+            // behind the others.  Everything read for tap t + 1 during tap t was waited for one tap ago.
             const auto tap = [&](auto T) {
                 constexpr int t = decltype(T)::value;
                 constexpr int tn = (t + 1) % 9;
                 const int slot_w = slot == 0 ? R - 1 : slot - 1;
+                const int slot_n = slot + 1 == R ? 0 : slot + 1;
+                const int wnext = wlane + slot_n * SLOT_BYTES;
                 const unsigned wv = w_live ? lane16 : OOB;
-                int at_n = 0;
                 __builtin_amdgcn_s_barrier();
-                // fillers of K-step 0: the K-step 1 fragments of this tap (pixels, then weights), D DMA slots, the
-                // next tap's addresses; filler f rides behind MFMA f * NM / (D + 3)
-                const auto filler0 = [&](auto Fc) {
-                    constexpr int f = decltype(Fc)::value;
-                    if constexpr (f == 0) {
-#pragma unroll
-                        for (int i = 0; i < MREP; ++i) xb[i] = lds16((selx[i] ^ 32) + i * 2048);
-                    } else if constexpr (f == 1) {
-#pragma unroll
-                        for (int j = 0; j < NREP; ++j) wb[j] = lds16((wcur ^ 32) + j * 2048);
-                    } else if constexpr (f < 2 + D) {
-                        // ---- DMA slot d: the next weight slice of the stream into the ring slot tap g - 1 left,
-                        // or one block of the next input range
-                        constexpr int d = f - 2;
-                        constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
-                        constexpr bool a_tap = t < ATAPS;
-                        const unsigned w_lds = s_wdst[d] + slot_w * SLOT_BYTES, w_soff = s_wsrc[d] + w_tile + gwoff;
-                        const int ia = t * A_SLOTS + s_aidx[d];
-                        const bool alive = a_tap && a_live && ia < na;
-                        const unsigned a_lds = alive ? lds0 + abuf_next + ia * 1024 : scratch;
-                        if constexpr (all_w) {
-                            dma16s(wt_rsrc, sgpr(w_lds), wv, sgpr(w_soff));
-                        } else if constexpr (all_a) {
-                            if constexpr (a_tap) {
+                static_for<0, NM>([&](auto Kc) {
+                    constexpr int k = decltype(Kc)::value;
+                    constexpr int j = k / MREP, i = k % MREP;
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wf[j], X[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                              0x7f7f7f7f);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the next tap's pixel fragment i behind MFMA i (tap 0 of the next chunk after tap 8; after the
+                    // tile's last tap they are read in vain: the next tile's lane masks are not known here)
+                    if constexpr (k < MREP) {
+                        constexpr int dy = tn / 3 - 1, dx = tn % 3 - 1;
+                        const bool v = (dy < 0 ? up[k] : dy > 0 ? dn[k] : true) && (dx < 0 ? lf[k] : dx > 0 ? rt[k] : true);
+                        Xn[k] = lds32((v ? at_n : zsel[k]) + k * 2048);
+                    }
+                    // weight fragment j has served its last MFMA of this tap: the next tap's takes its registers
+                    if constexpr (i == MREP - 1) Wf[j] = lds32(wnext + j * 2048);
+                    // DMA slot d behind MFMA 1 + d (when there are that many), the addresses behind the last but one
+                    static_for<0, D>([&](auto Dc) {
+                        constexpr int d = decltype(Dc)::value;
+                        if constexpr ((NM > D + 1 ? 1 + d : d * NM / D) == k) {
+                            constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
+                            constexpr bool a_tap = t < ATAPS;
+                            const unsigned w_lds = s_wdst[d] + slot_w * SLOT_BYTES, w_soff = s_wsrc[d] + w_tile + gwoff;
+                            const int ia = t * A_SLOTS + s_aidx[d];
+                            const bool alive = a_tap && a_live && ia < na;
+                            const unsigned a_lds = alive ? lds0 + abuf_next + ia * 1024 : scratch;
+                            if constexpr (all_w) {
+                                dma16s(wt_rsrc, sgpr(w_lds), wv, sgpr(w_soff));
+                            } else if constexpr (all_a) {
+                                if constexpr (a_tap) {
                                     unsigned av = in_off(a_pl, ia, a_cc);
                                     asm volatile("" : "+v"(av));   // computed unconditionally: a branch around it would split the tap's basic block
                                     dma16s(in_rsrc, sgpr(a_lds), alive ? av : OOB, 0u);
                                 }
-                        } else {
-                            const bool isw = s_isw[d];
-                            unsigned av = in_off(a_pl, ia, a_cc);
+                            } else {
+                                const bool isw = s_isw[d];
+                                unsigned av = in_off(a_pl, ia, a_cc);
                                 asm volatile("" : "+v"(av));   // computed unconditionally: a branch around it would split the tap's basic block
                                 av = (a_tap && alive) ? av : OOB;
-                            dma16s(s_rsrc[d], sgpr(isw ? w_lds : a_lds), isw ? wv : av, sgpr(isw ? w_soff : 0u));
+                                dma16s(s_rsrc[d], sgpr(isw ? w_lds : a_lds), isw ? wv : av, sgpr(isw ? w_soff : 0u));
+                            }
                         }
-                    } else {
-                        at_n = a_addr(t == 8 ? abuf_next : abuf, tn);
-                        const int slot_n = slot + 1 == R ? 0 : slot + 1;
-                        wcur = wlane + slot_n * SLOT_BYTES;
+                    });
+                    if constexpr (k == NM - 1) {
+                        constexpr int t2 = (t + 2) % 9;
+                        at_n = a_addr(t + 2 >= 9 ? abuf_next : abuf, t2);
                         slot = slot_n;
                     }
-                };
-                static_for<0, NM>([&](auto Kc) {
-                    constexpr int k = decltype(Kc)::value;
-                    acc[k / NREP][k % NREP] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[k % NREP], xa[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    static_for<0, D + 3>([&](auto Fc) {
-                        if constexpr (decltype(Fc)::value * NM / (D + 3) == k) filler0(Fc);
-                    });
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                static_for<0, NM>([&](auto Kc) {
-                    constexpr int k = decltype(Kc)::value;
-                    acc[k / NREP][k % NREP] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[k % NREP], xb[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (k == 0) {
-                        // K-step 0 fragments of the next tap (tap 0 of the next chunk after tap 8): legal before the
-                        // next barrier because that slice was waited for one tap ago.  (After the tile's last tap
-                        // they are read in vain: the next tile's lane masks are not known here.)
-                        constexpr int dy = tn / 3 - 1, dx = tn % 3 - 1;
-#pragma unroll
-                        for (int i = 0; i < MREP; ++i) {
-                            const bool v = (dy < 0 ? up[i] : dy > 0 ? dn[i] : true) && (dx < 0 ? lf[i] : dx > 0 ? rt[i] : true);
-                            selx[i] = v ? at_n : zsel[i];
-                            xa[i] = lds16(selx[i] + i * 2048);
-                        }
-                    }
-                    if constexpr (k == (NM > 1 ? 1 : 0)) {
-#pragma unroll
-                        for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                // DMAs issued R - 3 taps ago (and earlier) have landed -- and, behind an epilogue, its stores, which
-                // are older than this tap's DMAs (loads and stores retire in order)
                 constexpr int pending = [] {
                     int n = 0;
                     for (int k = 0; k < R - 3; ++k) {
@@ -360,7 +322,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
                     return n;
                 }();
                 wait_vm<pending>();
-                // advance the weight stream; behind a tile's last slice comes the first one of the next tile
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) X[i] = Xn[i];   // renamed away inside the unrolled chunk
                 // (selects, not a branch: a tap must stay one basic block, or the scheduling pins above do not hold
                 // the MFMAs in place and the compiler sinks them towards the end of the chunk)
                 const unsigned wrap = 0u - (unsigned)(gw + 1 == (unsigned)total);   // all ones behind the tile's last slice
@@ -396,8 +359,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
                     for (int gq = 0; gq < 4; ++gq) {
                         const int n = n0 + (wn * NREP + j) * 32 + gq * 8 + cq;
                         const float4 b = *(const float4*)(a.bias + n);
-                        float v[4] = {acc[i][j][gq * 4 + 0] + b.x, acc[i][j][gq * 4 + 1] + b.y, acc[i][j][gq * 4 + 2] + b.z,
-                                      acc[i][j][gq * 4 + 3] + b.w};
+                        const float4 sc = *(const float4*)(a.wscale + n);
+                        float v[4] = {acc[i][j][gq * 4 + 0] * sc.x + b.x, acc[i][j][gq * 4 + 1] * sc.y + b.y, acc[i][j][gq * 4 + 2] * sc.z + b.z,
+                                      acc[i][j][gq * 4 + 3] * sc.w + b.w};
                         if (a.act) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = silu_t(v[r]);
@@ -437,11 +401,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const float4 b = *(const float4*)(a.bias + nb + h * 8 + cq);
+                        const float4 sc = *(const float4*)(a.wscale + nb + h * 8 + cq);
                         const int r0 = (gp * 2 + h) * 4;
-                        v[h * 4 + 0] = acc[i][j][r0 + 0] + b.x;
-                        v[h * 4 + 1] = acc[i][j][r0 + 1] + b.y;
-                        v[h * 4 + 2] = acc[i][j][r0 + 2] + b.z;
-                        v[h * 4 + 3] = acc[i][j][r0 + 3] + b.w;
+                        v[h * 4 + 0] = acc[i][j][r0 + 0] * sc.x + b.x;
+                        v[h * 4 + 1] = acc[i][j][r0 + 1] * sc.y + b.y;
+                        v[h * 4 + 2] = acc[i][j][r0 + 2] * sc.z + b.z;
+                        v[h * 4 + 3] = acc[i][j][r0 + 3] * sc.w + b.w;
                     }
                     if (a.act) {
 #pragma unroll
@@ -514,91 +479,167 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     wait_vm<0>();
 }
 
-struct T32Tile {
+
+// f16 NHWC view (pixel pitch cs, first channel co, C channels) -> e4m3 rows of `pitch` bytes, zero beyond C
+__global__ __launch_bounds__(256) void quant_f8_kernel(const __half* __restrict__ in, int cs, int co, int C, unsigned char* __restrict__ out,
+                                                        int pitch, long npix) {
+    const int groups = pitch / 16;   // 16 channels per thread
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npix * groups) return;
+    const long p = idx / groups;
+    const int g = (int)(idx % groups);
+    union {
+        uint4 u[2];
+        _Float16 h[16];
+    } x;
+    const int c0 = g * 16;
+    if (c0 + 16 <= C) {
+        const uint4* src = (const uint4*)(in + p * cs + co + c0);
+        x.u[0] = src[0];
+        x.u[1] = src[1];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x.h[e] = c0 + e < C ? (_Float16)in[p * cs + co + c0 + e] : (_Float16)0.f;
+    }
+    union {
+        uint4 u;
+        int w[4];
+    } o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32((float)x.h[4 * e + 0], (float)x.h[4 * e + 1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32((float)x.h[4 * e + 2], (float)x.h[4 * e + 3], w, true);
+        o.w[e] = w;
+    }
+    *(uint4*)(out + p * pitch + c0) = o.u;
+}
+
+struct T32F8Tile {
     int bm, bn, threads, a_slots, ring, nrep, epi, wgs_per_cu;
     void (*kernel)(const ConvArgs, int, int, int);
 };
 
-#define T32(WM, WN, MR, NR, AS, R, EPI, WPC) \
-    { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, NR, EPI, WPC, conv_t32_kernel<WM, WN, MR, NR, AS, R, EPI> }
+#define T32F8(WM, WN, MR, NR, AS, R, EPI, WPC) \
+    { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, NR, EPI, WPC, conv_t32f8_kernel<WM, WN, MR, NR, AS, R, EPI, WPC> }
 
-const T32Tile kT32Tiles[] = {
-    // one workgroup per CU (up to 256 VGPRs)
-    T32(4, 2, 2, 3, 4, 5, 1, 1),    // 0: 256 x 192, 40-wide maps (22 input blocks over 6 taps), rows leave through LDS
-    T32(4, 2, 2, 3, 4, 4, 1, 1),    // 1: 256 x 192, up to 80-wide maps (27 blocks over 7 taps)
-    T32(4, 2, 2, 3, 4, 5, 0, 1),    // 2: as 0 with lane-pair stores
-    T32(8, 1, 2, 3, 10, 5, 0, 1),   // 3: 512 x 96
-    T32(4, 2, 2, 4, 8, 4, 0, 1),    // 4: 256 x 256 (fused head convs)
-    T32(8, 1, 2, 2, 12, 5, 0, 1),   // 5: 512 x 64
-    // two workgroups per CU (<= 128 VGPRs, <= 80 KiB of LDS): one's epilogue under the other's K loop
-    T32(8, 1, 1, 3, 10, 4, 0, 2),   // 6: 256 x 96
-    T32(8, 1, 1, 2, 12, 4, 0, 2),   // 7: 256 x 64
-    T32(4, 2, 1, 3, 4, 4, 0, 2),    // 8: 128 x 192
+const T32F8Tile kT32F8Tiles[] = {
+    T32F8(4, 2, 2, 3, 4, 5, 0, 1),    // 0: 256 x 192, 40-wide maps
+    T32F8(4, 2, 2, 3, 4, 4, 0, 1),    // 1: 256 x 192, up to 80-wide maps
+    T32F8(8, 1, 2, 3, 10, 5, 0, 1),   // 2: 512 x 96
+    T32F8(4, 2, 2, 4, 8, 4, 0, 1),    // 3: 256 x 256 (fused head convs)
+    T32F8(8, 1, 2, 2, 12, 5, 0, 1),   // 4: 512 x 64
+    T32F8(8, 1, 1, 3, 10, 4, 0, 2),   // 5: 256 x 96, two workgroups per CU
+    T32F8(4, 2, 1, 3, 4, 4, 0, 2),    // 6: 128 x 192, two workgroups per CU
+    T32F8(8, 1, 1, 2, 12, 4, 0, 2),   // 7: 256 x 64, two workgroups per CU
 };
-constexpr int kNumT32Tiles = sizeof(kT32Tiles) / sizeof(kT32Tiles[0]);
+constexpr int kNumT32F8Tiles = sizeof(kT32F8Tiles) / sizeof(kT32F8Tiles[0]);
 
-int t32_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
-int t32_lds_bytes(const T32Tile& t, int W) {
-    return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + (t.epi ? (t.threads / 64) * 32 * (t.nrep * 64 + 16) : 0);
-}
+int f8_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
+int f8_lds_bytes(const T32F8Tile& t, int W) { return 2 * f8_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024; }
 
 }  // namespace
 
-int conv_t32_num_tiles() { return kNumT32Tiles; }
-ConvTile conv_t32_tile(int id) { return ConvTile{kT32Tiles[id].bm, kT32Tiles[id].bn, 32}; }
+int conv_t32f8_num_tiles() { return kNumT32F8Tiles; }
+ConvTile conv_t32f8_tile(int id) { return ConvTile{kT32F8Tiles[id].bm, kT32F8Tiles[id].bn, 64}; }
 
-bool conv_t32_supported(const ConvArgs& a, int tile) {
-    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 32 || a.Cin < 32) return false;
-    if (a.Ho != a.H || a.Wo != a.W || a.pre || a.in_slab_c || a.out_slab_c || !a.wt_t32) return false;
+bool conv_t32f8_supported(const ConvArgs& a, int tile) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 16 || a.Cin < 32) return false;
+    if (a.Ho != a.H || a.Wo != a.W || a.pre || a.in_slab_c || a.out_slab_c || !a.wt8 || !a.in8 || !a.wscale) return false;
     if (tile < 0) return true;
-    const T32Tile& t = kT32Tiles[tile];
-    const int na = t32_rows(t.bm, a.W) / 16;
-    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && t32_lds_bytes(t, a.W) <= 160 * 1024 / t.wgs_per_cu;
+    const T32F8Tile& t = kT32F8Tiles[tile];
+    const int na = f8_rows(t.bm, a.W) / 16;
+    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && f8_lds_bytes(t, a.W) <= 160 * 1024 / t.wgs_per_cu;
 }
 
-void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
-    if (tile < 0 || tile >= kNumT32Tiles) fail(RMR_ERR_INVALID_ARGUMENT, "conv_t32: tile %d out of range", tile);
-    if (!conv_t32_supported(a, tile)) fail(RMR_ERR_LOGIC, "conv_t32: layer not supported by tile %d", tile);
-    const T32Tile& t = kT32Tiles[tile];
-    if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4) fail(RMR_ERR_LOGIC, "conv_t32: misaligned view");
-    if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull || a.wt_t32_bytes == 0)
-        fail(RMR_ERR_LOGIC, "conv_t32: buffer sizes not set or input view larger than 3.75 GiB");
+void launch_quant_f8(DeviceCtx& ctx, hipStream_t stream, const __half* in, int cs, int co, int C, unsigned char* out, int pitch, long npix) {
+    if (pitch % 16 || pitch < C || cs % 8 || co % 8) fail(RMR_ERR_LOGIC, "quant_f8: misaligned view");
+    const long n = npix * (pitch / 16);
+    ProfScope ps(ctx.prof, stream, "quant_f8");
+    quant_f8_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(in, cs, co, C, out, pitch, npix);
+    RMR_HIP(hipGetLastError());
+}
+
+void launch_conv_t32f8(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
+    if (tile < 0 || tile >= kNumT32F8Tiles) fail(RMR_ERR_INVALID_ARGUMENT, "conv_t32f8: tile %d out of range", tile);
+    if (!conv_t32f8_supported(a, tile)) fail(RMR_ERR_LOGIC, "conv_t32f8: layer not supported by tile %d", tile);
+    const T32F8Tile& t = kT32F8Tiles[tile];
+    if (a.in8_cs % 64 || a.out_cs % 4 || a.out_co % 4) fail(RMR_ERR_LOGIC, "conv_t32f8: misaligned view");
+    if (a.in8_bytes == 0 || a.in8_bytes > 0xf0000000ull || a.wt8_bytes == 0)
+        fail(RMR_ERR_LOGIC, "conv_t32f8: buffer sizes not set or input view larger than 3.75 GiB");
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const T32Tile& d : kT32Tiles)
+        for (const T32F8Tile& d : kT32F8Tiles)
             (void)hipFuncSetAttribute((const void*)d.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    const int rows = t32_rows(t.bm, a.W);
-    const int lds = t32_lds_bytes(t, a.W);
+    const int rows = f8_rows(t.bm, a.W);
+    const int lds = f8_lds_bytes(t, a.W);
     const int n_tiles = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
-    // persistent: at most wgs_per_cu workgroups per CU (a multiple of 8: a workgroup stays on its XCD), each walks tiles
     const int grid = std::min((n_tiles + 7) / 8 * 8, ctx.num_cus * t.wgs_per_cu);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
-    const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
+    const double bytes = (double)a.N * a.H * a.W * a.Cin + 2.0 * (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K;
     static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
     static std::mutex name_mu;
     static std::map<std::string, std::string> names;
-    const char* pname = "conv_igemm_f16";
+    const char* pname = "conv_igemm_f8";
     if (per_layer && ctx.prof.on) {
         char buf[48];
-        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d g%d", a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
+        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d f%d", a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
         std::lock_guard<std::mutex> lk(name_mu);
         pname = names.emplace(buf, buf).first->second.c_str();
     }
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
-    // half a tile of head start for one workgroup of each CU pair: ~500 cycles per tap, in units of 4096 cycles
-    static const int stagger_env = std::getenv("RMR_T32_STAGGER") ? std::atoi(std::getenv("RMR_T32_STAGGER")) : -1;
-    const int taps = a.Cin / 32 * 9;
-    const int stagger = t.wgs_per_cu < 2 || grid <= ctx.num_cus ? 0 : stagger_env >= 0 ? stagger_env : (taps * 500 + 4095) / 4096;
-    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, stagger);
+    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, 0);
     RMR_HIP(hipGetLastError());
 }
 
-// [Cout_pad][Kp] (k = tap * Cin + ci) -> [chunk][tap][Cout_pad / 16][64 lanes][8]: the LDS image of every
-// (chunk, tap) slice in the order the DMA writes it (lane l: row l >> 2, slot l & 3 holds chunk slot ^ key(row))
-void pack_conv_weights_t32(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out) {
-    const int chunks = cin / 32, nblk = cout_pad / 16;
-    out.assign((size_t)chunks * 9 * nblk * 512, __float2half(0.f));
+// ---- e4m3 on the host -----------------------------------------------------------------------------------
+// OCP e4m3fn: 1 sign, 4 exponent bits (bias 7), 3 mantissa bits; no infinities, 0x7f / 0xff = NaN, largest
+// finite value 448; round to nearest even, values beyond 448 saturate (the weights are scaled so that none is)
+unsigned char f32_to_e4m3(float x) {
+    if (std::isnan(x)) return 0x7f;
+    const unsigned char sign = std::signbit(x) ? 0x80 : 0;
+    float a = std::fabs(x);
+    if (a >= 464.f) return sign | 0x7e;             // 448 is the largest finite value (464 = the midpoint to 480)
+    if (a < 0.0009765625f) return sign;             // below half of the smallest subnormal 2^-9
+    int e;
+    std::frexp(a, &e);                              // a = m * 2^e, m in [0.5, 1)
+    int exp = e - 1;                                // a = 1.f * 2^exp
+    if (exp < -6) exp = -6;                         // subnormal range: fixed exponent, no hidden bit
+    const float q = std::ldexp(1.0f, exp - 3);      // value of one mantissa step
+    float steps = a / q;                            // exact: a power-of-two scaling
+    float r = std::nearbyint(steps);                // round half to even (default rounding mode)
+    float v = r * q;
+    if (v > 448.f) v = 448.f;
+    // re-derive exponent and mantissa of the rounded value
+    if (v < 0.015625f) return sign | (unsigned char)std::lrint(v / 0.001953125f);   // subnormal: mantissa = v / 2^-9
+    int e2;
+    const float m2 = std::frexp(v, &e2);            // v = m2 * 2^e2, m2 in [0.5, 1)
+    const int be = e2 - 1 + 7;
+    const int man = (int)std::lrint((m2 * 2.f - 1.f) * 8.f);
+    return sign | (unsigned char)((be << 3) | man);
+}
+
+float e4m3_to_f32(unsigned char b) {
+    const int be = (b >> 3) & 15, man = b & 7;
+    if (be == 15 && man == 7) return std::nanf("");
+    const float v = be == 0 ? std::ldexp((float)man, -9) : std::ldexp(1.f + man / 8.f, be - 7);
+    return b & 0x80 ? -v : v;
+}
+
+// [Cout_pad][Kp] f16 (k = tap * Cin + ci) -> e4m3 with one scale per output channel (the largest |w| of a row
+// becomes 448), as the LDS images of the (64-channel chunk, tap) slices:
+// [chunk][tap][Cout_pad / 16][64 lanes][16]: lane l = row l >> 2, slot l & 3 holds channels 16 (slot ^ key(row)) ..
+void pack_conv_weights_t32f8(const __half* packed, int cout_pad, int cin, int Kp, std::vector<unsigned char>& out,
+                             std::vector<float>& scale) {
+    const int chunks = (cin + 63) / 64, nblk = cout_pad / 16;
+    out.assign((size_t)chunks * 9 * nblk * 1024, 0);
+    scale.assign(cout_pad, 1.f);
+    for (int n = 0; n < cout_pad; ++n) {
+        float mx = 0.f;
+        for (int k = 0; k < 9 * cin; ++k) mx = std::max(mx, std::fabs(__half2float(packed[(size_t)n * Kp + k])));
+        scale[n] = mx > 0.f ? mx / 448.f : 1.f;
+    }
     for (int cc = 0; cc < chunks; ++cc)
         for (int t = 0; t < 9; ++t)
             for (int b = 0; b < nblk; ++b)
@@ -606,9 +647,11 @@ void pack_conv_weights_t32(const __half* packed, int cout_pad, int cin, int Kp, 
                     const int r = l >> 2, s = l & 3;
                     const int n = b * 16 + r;
                     const int c = s ^ ((r >> 2) & 3);
-                    const __half* src = packed + (size_t)n * Kp + (size_t)t * cin + cc * 32 + c * 8;
-                    __half* dst = out.data() + ((((size_t)cc * 9 + t) * nblk + b) * 64 + l) * 8;
-                    for (int e = 0; e < 8; ++e) dst[e] = src[e];
+                    unsigned char* dst = out.data() + ((((size_t)cc * 9 + t) * nblk + b) * 64 + l) * 16;
+                    for (int e = 0; e < 16; ++e) {
+                        const int ci = cc * 64 + c * 16 + e;
+                        dst[e] = ci < cin ? f32_to_e4m3(__half2float(packed[(size_t)n * Kp + (size_t)t * cin + ci]) / scale[n]) : 0;
+                    }
                 }
 }
 

@@ -288,3 +288,40 @@ def test_conv_t32_every_tile(rmr):
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 4, 4, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
                    False, tile=806)  # Cin = 48 is not a multiple of 32
+
+
+def _e4m3(a):
+    """OCP e4m3fn rounding (nearest even, saturating), as the packer and the device quantiser do it"""
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).clamp(-448, 448).to(torch.float8_e4m3fn).float().numpy()
+
+
+def run_case_f8(rmr, n, h, w, cin, cout, silu, res, tile, seed=0):
+    """conv_t32f8 against plain PyTorch fp32 conv2d on the SAME e4m3 operands: inputs rounded to f16 and then
+    to e4m3 (unit scale), weights rounded to f16, divided by their row's scale max|w| / 448, rounded to e4m3 --
+    so that only the f32 accumulation order differs (2e-3 of the output scale, as for the f16 kernels)."""
+    rng = np.random.default_rng(seed)
+    x = r16(rng.normal(0, 1, (n, h, w, cin)).astype(np.float32))
+    wt = r16((rng.normal(0, 1, (cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+    b = rng.normal(0, 0.5, cout).astype(np.float32)
+    r = r16(rng.normal(0, 1, (n, h, w, cout)).astype(np.float32)) if res else None
+    got = rmr.conv2d(x, wt, b, 1, 1, silu, r, tile=tile)
+    scale = (np.abs(wt).reshape(cout, -1).max(1) / np.float32(448.0)).astype(np.float32)
+    wq = _e4m3(wt / scale[:, None, None, None]) * scale[:, None, None, None]
+    want = ref_conv(_e4m3(x), wq.astype(np.float32), b, 1, 1, silu, r)
+    err = np.abs(got - want).max()
+    assert err <= 2e-3 * max(1.0, np.abs(want).max()), f"max err {err}"
+    # and the quantisation itself is not the identity: the f16 result differs visibly
+    assert np.abs(got - ref_conv(x, wt, b, 1, 1, silu, r)).max() > 5e-3
+
+
+def test_conv_t32f8_every_tile(rmr):
+    # the fp8 form of conv_t32 (conv_t32f8.hip, ids 900..): e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4
+    tiles = [(256, 192), (256, 192), (512, 96), (256, 256), (512, 64), (256, 96), (128, 192), (256, 64)]
+    for t, (bm, bn) in enumerate(tiles):
+        run_case_f8(rmr, 3, 20, 20, 64, bn, True, True, 900 + t, seed=t)             # one 64-channel chunk
+        run_case_f8(rmr, 1, 19, 23, 96, bn * 2, True, False, 900 + t, seed=40 + t)   # 1.5 chunks: zero-padded tail, odd W
+    run_case_f8(rmr, 2, 40, 40, 192, 192, True, True, 900, seed=70)     # 3 chunks
+    run_case_f8(rmr, 1, 80, 80, 96, 96, True, True, 902, seed=71)       # 512-row tiles on 80-wide maps
+    run_case_f8(rmr, 2, 20, 20, 288, 288, True, True, 905, seed=72)     # 4.5 chunks, 3 channel tiles
+    run_case_f8(rmr, 1, 5, 5, 32, 96, False, False, 905, seed=73)       # half a chunk, tile far larger than the image
+    run_case_f8(rmr, 300, 20, 20, 64, 192, True, True, 906, seed=74)    # workgroups walk several tiles
