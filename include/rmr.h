@@ -182,6 +182,10 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
  * (conv_t32f8.hip; the counterpart of choosing kFP16 / kINT8 at detector.cpp:208-231). */
 rmr_status rmr_f32_to_e4m3(const float* x, int n, unsigned char* out);
 
+/* The device quantiser of the fp8 plan (f16 -> e4m3, unit scale) on host data, n a multiple of 16: parity
+ * hook, must equal rmr_f32_to_e4m3 of the f16-rounded values. */
+rmr_status rmr_quant_e4m3(int device, const float* x, int n, unsigned char* out);
+
 /* Development hook: times one conv layer (bias + SiLU, f16 in / f16 out, optional residual) on
  * device-resident pseudo-random data with HIP events; kernel = a tiled family id as in rmr_conv2d
  * (0..299, 800..899).  *ms_out = mean launch time over `reps` launches.  No reference counterpart
@@ -192,6 +196,12 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
 /* ---------------------------------------------------------------- Detector */
 
 typedef struct rmr_detector rmr_detector;
+
+/* Arithmetic of the network (the reference sets one TensorRT builder flag, detector.cpp:226: kFP16):
+ * F16 = f16 operands everywhere (f32 accumulate); FP8 = BASELINE configs[4]: the 3x3 / stride-1 convolutions
+ * with >= 64 input channels (~70 % of the FLOPs) take OCP e4m3 weights (one scale per output channel) and e4m3
+ * activations on the MX MFMA, everything else and every stored activation stay f16. */
+enum { RMR_PRECISION_F16 = 0, RMR_PRECISION_FP8 = 1 };
 
 /* Detector::Detector arguments (detector.h:87-93).  engine_path names this library's
  * weight pack (*.rmrw, see rm_radar_amd/weights.py) instead of a TensorRT engine. */
@@ -205,6 +215,7 @@ typedef struct {
     int input_width, input_height; /* 640 x 640 */
     int input_channels;            /* 3 */
     int device;                    /* the reference hard-wires cudaSetDevice(0) (detector.cpp:61) */
+    int precision;                 /* RMR_PRECISION_*: the builder flag of detector.cpp:226 (kFP16 there)  */
 } rmr_detector_cfg;
 
 void rmr_detector_cfg_default(rmr_detector_cfg* cfg);
@@ -246,6 +257,7 @@ typedef struct {
     int input_width, input_height, input_channels;
     int device;
     int max_frames;                           /* frames per detect_batch call (>=1) */
+    int precision;                            /* RMR_PRECISION_* for both networks */
 } rmr_robot_detector_cfg;
 
 void rmr_robot_detector_cfg_default(rmr_robot_detector_cfg* cfg);

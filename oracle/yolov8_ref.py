@@ -12,6 +12,12 @@ as plain PyTorch fp32 functional ops on the CPU, reading the same weight pack th
 the HIP engine stores f16 (f32 accumulate, f32 bias/SiLU/residual, one rounding per stored
 tensor; the two final 1x1 head convs stay f32), which isolates accumulation-order noise from
 precision loss.
+
+``fp8=True`` (implies emulate_f16) restates the engine's RMR_PRECISION_FP8 plan (BASELINE configs[4]): the
+3x3 / stride-1 convolutions with >= 64 input channels (a multiple of 16) see their f16 input rounded to OCP
+e4m3 (unit scale) and their f16 weights divided by max|w| / 448 of the output channel, rounded to e4m3 and
+scaled back; everything else is as in the f16 mode (the Detect head's 3x3 convolutions included, unless
+RMR_FP8_HEAD=1, the engine's switch).
 """
 from __future__ import annotations
 
@@ -24,11 +30,20 @@ def _r16(t):
     return t.half().float()
 
 
+def _e4m3(t):
+    """OCP e4m3fn, round to nearest even, saturating at 448 (what the weight packer and v_cvt_pk_fp8_f32 do)"""
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
 class YoloV8Ref:
-    def __init__(self, tensors, meta, emulate_f16=False):
+    def __init__(self, tensors, meta, emulate_f16=False, fp8=False):
         from rm_radar_amd import weights as W  # layer-plan arithmetic only (numpy)
         self.meta = meta
-        self.f16 = emulate_f16
+        self.f16 = emulate_f16 or fp8
+        self.fp8 = fp8
+        import os
+        self.fp8_head = os.environ.get("RMR_FP8_HEAD", "0") not in ("", "0")   # the engine's switch: Detect convs too
+        emulate_f16 = self.f16
         self.arch = W.arch(meta["scale"], meta["nc"])
         self.nc = meta["nc"]
         self.t = {}
@@ -42,6 +57,10 @@ class YoloV8Ref:
     def conv(self, name, x, k, s=1, act=True, residual=None, keep_f32=False):
         w = self.t[name + ".weight"]
         b = self.t[name + ".bias"]
+        if self.fp8 and k == 3 and s == 1 and w.shape[1] >= 64 and w.shape[1] % 16 == 0 and (self.fp8_head or not name.startswith("model.22.")):
+            x = _e4m3(x)
+            scale = (w.abs().flatten(1).max(1).values / 448.0).clamp_min(1e-30).view(-1, 1, 1, 1)
+            w = _e4m3(w / scale) * scale
         y = F.conv2d(x, w, b, stride=s, padding=k // 2)
         if act:
             y = y * torch.sigmoid(y)
@@ -151,7 +170,7 @@ class YoloV8Ref:
         return self.decode_head(box, cls, shapes).numpy()
 
 
-def load(path, emulate_f16=False):
+def load(path, emulate_f16=False, fp8=False):
     from rm_radar_amd import weights as W
     tensors, meta = W.load_pack(path)
-    return YoloV8Ref(tensors, meta, emulate_f16)
+    return YoloV8Ref(tensors, meta, emulate_f16, fp8)

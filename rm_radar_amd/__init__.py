@@ -274,7 +274,7 @@ class Detector:
 
     def __init__(self, engine_path, classes, image_size, max_batch_size, opt_batch_size=None,
                  nms_thresh=0.65, conf_thresh=0.25, input_width=640, input_height=640,
-                 input_name="images", input_channels=3, opt_level=3, device=0):
+                 input_name="images", input_channels=3, opt_level=3, device=0, precision="f16"):
         cfg = _lib.DetectorCfg()
         lib().rmr_detector_cfg_default(C.byref(cfg))
         from .onnx_import import ensure_pack  # detector.cpp:74-99: build from the sibling .onnx when missing
@@ -288,6 +288,7 @@ class Detector:
         cfg.input_width, cfg.input_height = input_width, input_height
         cfg.input_channels = input_channels
         cfg.device = device
+        cfg.precision = {"f16": 0, "fp8": 1}[precision]
         self.classes = classes
         self._h = C.c_void_p()
         check(lib().rmr_detector_create(C.byref(cfg), C.byref(self._h)))
@@ -341,7 +342,7 @@ class RobotDetector:
                  opt_cars, iou_thresh=0.75, car_nms_thresh=0.65, car_conf_thresh=0.25,
                  armor_nms_thresh=0.65, armor_conf_thresh=0.50, input_width=640,
                  input_height=640, input_name="images", input_channels=3, opt_level=5,
-                 device=0, max_frames=1):
+                 device=0, max_frames=1, precision="f16"):
         cfg = _lib.RobotDetectorCfg()
         lib().rmr_robot_detector_cfg_default(C.byref(cfg))
         from .onnx_import import ensure_pack
@@ -357,6 +358,7 @@ class RobotDetector:
         cfg.input_channels = input_channels
         cfg.device = device
         cfg.max_frames = max_frames
+        cfg.precision = {"f16": 0, "fp8": 1}[precision]
         self.max_cars = max_cars
         self._h = C.c_void_p()
         check(lib().rmr_robot_detector_create(C.byref(cfg), C.byref(self._h)))

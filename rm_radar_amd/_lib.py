@@ -70,7 +70,7 @@ class DetectorCfg(C.Structure):
                 ("image_height", C.c_int), ("max_batch_size", C.c_int),
                 ("opt_batch_size", C.c_int), ("nms_thresh", C.c_float),
                 ("conf_thresh", C.c_float), ("input_width", C.c_int), ("input_height", C.c_int),
-                ("input_channels", C.c_int), ("device", C.c_int)]
+                ("input_channels", C.c_int), ("device", C.c_int), ("precision", C.c_int)]
 
 
 class RobotDetectorCfg(C.Structure):
@@ -80,7 +80,7 @@ class RobotDetectorCfg(C.Structure):
                 ("car_nms_thresh", C.c_float), ("car_conf_thresh", C.c_float),
                 ("armor_nms_thresh", C.c_float), ("armor_conf_thresh", C.c_float),
                 ("input_width", C.c_int), ("input_height", C.c_int), ("input_channels", C.c_int),
-                ("device", C.c_int), ("max_frames", C.c_int)]
+                ("device", C.c_int), ("max_frames", C.c_int), ("precision", C.c_int)]
 
 
 class LocatorCfg(C.Structure):
@@ -132,6 +132,7 @@ SYMBOLS = {
                    [_fp, _fp, C.c_int]),
     "rmr_conv_bench": (C.c_int, [C.c_int] * 11 + [_fp]),
     "rmr_f32_to_e4m3": (C.c_int, [_fp, C.c_int, _vp]),
+    "rmr_quant_e4m3": (C.c_int, [C.c_int, _fp, C.c_int, _vp]),
     "rmr_stream_owner": (C.c_int, [C.c_int, C.c_int]),
     "rmr_streams_of_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, C.c_int]),
     "rmr_comm_unique_id": (C.c_int, [C.c_int, C.c_char_p]),

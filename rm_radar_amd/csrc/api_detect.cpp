@@ -294,6 +294,25 @@ rmr_status rmr_f32_to_e4m3(const float* x, int n, unsigned char* out) {
     });
 }
 
+// The device quantiser of the fp8 plan on host data: x[n] (rounded to f16 first, as activations are stored) ->
+// e4m3 bytes, n a multiple of 16.  Parity hook for tests (must equal rmr_f32_to_e4m3 of the f16 values).
+rmr_status rmr_quant_e4m3(int device, const float* x, int n, unsigned char* out) {
+    return guarded([&] {
+        if (!x || !out || n <= 0 || n % 16) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_quant_e4m3: n must be a positive multiple of 16");
+        DeviceCtx& ctx = device_ctx(device);
+        std::vector<__half> h(n);
+        for (int i = 0; i < n; ++i) h[i] = __float2half(x[i]);
+        DevBuf<__half> dx;
+        DevBuf<unsigned char> dq;
+        dx.alloc(n);
+        dq.alloc(n);
+        RMR_HIP(hipMemcpy(dx.p, h.data(), (size_t)n * 2, hipMemcpyHostToDevice));
+        launch_quant_f8(ctx, ctx.stream, dx.p, 16, 0, 16, dq.p, 16, n / 16);
+        RMR_HIP(hipStreamSynchronize(ctx.stream));
+        RMR_HIP(hipMemcpy(out, dq.p, n, hipMemcpyDeviceToHost));
+    });
+}
+
 // One layer on device-resident f16 data, timed with HIP events: the kernel-development loop (tools/conv_bench.py).
 // x: random f16 NHWC (one image's worth replicated), f16 output, optional residual; `tile` as in rmr_conv2d
 // (only the tiled families: 0..299, 800..899).  ms_out = mean launch time over `reps` launches.

@@ -505,11 +505,13 @@ __global__ __launch_bounds__(256) void quant_f8_kernel(const __half* __restrict_
         uint4 u;
         int w[4];
     } o;
+    // the conversion turns what lies beyond e4m3's range into NaN: saturate at +-448 first, as the packer does
+    const auto sat = [](_Float16 v) { return __builtin_amdgcn_fmed3f((float)v, -448.f, 448.f); };
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         int w = 0;
-        w = __builtin_amdgcn_cvt_pk_fp8_f32((float)x.h[4 * e + 0], (float)x.h[4 * e + 1], w, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32((float)x.h[4 * e + 2], (float)x.h[4 * e + 3], w, true);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(sat(x.h[4 * e + 0]), sat(x.h[4 * e + 1]), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(sat(x.h[4 * e + 2]), sat(x.h[4 * e + 3]), w, true);
         o.w[e] = w;
     }
     *(uint4*)(out + p * pitch + c0) = o.u;

@@ -66,8 +66,10 @@ Detector::Detector(const rmr_detector_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg
     int prio_lo = 0, prio_hi = 0;
     RMR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     RMR_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio_hi));
+    if (cfg.precision != RMR_PRECISION_F16 && cfg.precision != RMR_PRECISION_FP8)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Detector: precision %d is not one of RMR_PRECISION_*", cfg.precision);
     net_ = std::make_unique<Yolov8>(ctx_, cfg.engine_path, cfg.classes, cfg.input_width, cfg.input_height,
-                                    cfg.max_batch_size);
+                                    cfg.max_batch_size, cfg.precision == RMR_PRECISION_FP8);
     const int B = cfg.max_batch_size;
     descs_dev_.alloc(B);
     pp_dev_.alloc(B);
@@ -210,6 +212,7 @@ static rmr_detector_cfg sub_cfg(const rmr_robot_detector_cfg& c, const char* pat
     d.input_height = c.input_height;
     d.input_channels = c.input_channels;
     d.device = c.device;
+    d.precision = c.precision;
     return d;
 }
 

@@ -37,8 +37,9 @@ struct View {
 class Yolov8 {
    public:
     // in_w/in_h: network input size (multiples of 32); max_batch: largest forward() batch
+    // fp8: the 3x3 / stride-1 layers with >= 64 input channels run on e4m3 operands (RMR_FP8=1 forces it)
     Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int in_w, int in_h,
-           int max_batch);
+           int max_batch, bool fp8 = false);
 
     int nc() const { return nc_; }
     int anchors() const { return anchors_; }
@@ -62,11 +63,13 @@ class Yolov8 {
     ~Yolov8();
 
    private:
-    enum OpKind { OP_CONV, OP_SPPF, OP_UP, OP_HEAD };
+    enum OpKind { OP_CONV, OP_SPPF, OP_UP, OP_HEAD, OP_QUANT };
     struct ConvW {
         DevBuf<__half> w;
         DevBuf<__half> w32;  // 3x3 layers with Cin % 32 == 0: the LDS images conv_t32 streams (pack_conv_weights_t32)
         DevBuf<float> b;
+        DevBuf<unsigned char> w8;  // fp8 plan: e4m3 LDS images (pack_conv_weights_t32f8) ...
+        DevBuf<float> wscale;      // ... and the scale of every output channel
         int cout = 0, cout_pad = 0, cin = 0, k = 0, K = 0, Kp = 0;
     };
     struct Op {
@@ -80,6 +83,11 @@ class Yolov8 {
         size_t in_slab_step = 0, out_slab_step = 0;
         bool in_is_input = false;
         bool out_f32 = false;
+        // fp8 plan: OP_CONV reads the e4m3 copy of `in` at q_off (bytes per image into arena8_, rows of q_pitch
+        // bytes); OP_QUANT writes it
+        bool fp8 = false;
+        size_t q_off = 0;
+        int q_pitch = 0;
         int stride = 1, act = 1;
         // OP_HEAD
         View box, cls;
@@ -121,6 +129,11 @@ class Yolov8 {
     size_t arena_halves_ = 0, arena_floats_ = 0;  // per image
     DevBuf<__half> arena_;
     DevBuf<float> arena32_;
+    DevBuf<unsigned char> arena8_;   // fp8 plan: quantised inputs of the e4m3 layers
+    size_t arena_bytes8_ = 0;        // per image
+    bool fp8_ = false;
+    bool fp8_layer_ = true;   // planner state: whether the layers being added may take e4m3 operands
+    std::vector<__half> last_packed_;  // add_conv_weights' packed f16 weights, for the e4m3 packer
     DevBuf<__half> input_;
     DevBuf<float> output_;
     // autotuned kernel choice per (op, images in the launch): 0..99 conv_igemm tile, 100..199

@@ -147,6 +147,15 @@ int Yolov8::add_conv_weights(const WeightPack& p, const std::string& name, int c
 
 // the second copy of a 3x3 layer's weights, as the LDS images conv_t32 streams
 void Yolov8::upload_t32(ConvW& cw, const std::vector<__half>& packed) {
+    if (fp8_ && fp8_layer_ && cw.k == 3 && cw.cin % 16 == 0 && cw.cin >= 64) {
+        std::vector<unsigned char> p8;
+        std::vector<float> ws;
+        pack_conv_weights_t32f8(packed.data(), cw.cout_pad, cw.cin, cw.Kp, p8, ws);
+        cw.w8.alloc(p8.size());
+        cw.wscale.alloc(ws.size());
+        RMR_HIP(hipMemcpy(cw.w8.p, p8.data(), p8.size(), hipMemcpyHostToDevice));
+        RMR_HIP(hipMemcpy(cw.wscale.p, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (cw.k != 3 || cw.cin % 32) return;
     std::vector<__half> p32;
     pack_conv_weights_t32(packed.data(), cw.cout_pad, cw.cin, cw.Kp, p32);
@@ -197,6 +206,21 @@ void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act
     op.conv = widx;
     op.in = in;
     op.out = out;
+    // fp8 plan: a 3x3 / stride-1 layer with e4m3 weights reads an e4m3 copy of its input, written just before it
+    // (the layers between keep f16 activations: the copy is one extra pass over a tensor the conv reads nine times)
+    if (cw.w8.p && stride == 1 && !in_is_input && !pre && in.h == out.h && in.w == out.w) {
+        Op q{};
+        q.kind = OP_QUANT;
+        q.in = in;
+        q.q_pitch = (cw.cin + 63) / 64 * 64;
+        q.q_off = arena_bytes8_;
+        arena_bytes8_ += (size_t)in.h * in.w * q.q_pitch;
+        arena_bytes8_ = (arena_bytes8_ + 255) & ~(size_t)255;
+        ops_.push_back(q);
+        op.fp8 = true;
+        op.q_off = q.q_off;
+        op.q_pitch = q.q_pitch;
+    }
     if (res) op.res = *res;
     if (pre) {
         if (pre->h * 2 != out.h || pre->w * 2 != out.w || pre->cs != cw.cout_pad || pre->co != 0 || cw.k != 1)
@@ -297,8 +321,8 @@ bool Yolov8::pw_can(int K, int N, int h, int w, bool pre) const {
 
 static int make_divisible(double x, int d) { return (int)std::ceil(x / d) * d; }
 
-Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int in_w, int in_h, int max_batch)
-    : ctx_(ctx), in_w_(in_w), in_h_(in_h), max_batch_(max_batch) {
+Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int in_w, int in_h, int max_batch, bool fp8)
+    : ctx_(ctx), in_w_(in_w), in_h_(in_h), max_batch_(max_batch), fp8_(fp8) {
     if (in_w <= 0 || in_h <= 0 || in_w % 32 || in_h % 32)
         fail(RMR_ERR_INVALID_ARGUMENT, "network input %dx%d must be a positive multiple of 32", in_w, in_h);
     if (max_batch < 1) fail(RMR_ERR_INVALID_ARGUMENT, "max_batch_size must be >= 1");
@@ -316,6 +340,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     if (const char* e = std::getenv("RMR_FUSE_LB")) fuse_lb_ = atoi(e) != 0;
     if (const char* e = std::getenv("RMR_FUSE_UP")) fuse_up_ = atoi(e) != 0;
     if (const char* e = std::getenv("RMR_SLABS")) slabs_ = atoi(e) != 0;
+    if (const char* e = std::getenv("RMR_FP8")) fp8_ = fp8_ || atoi(e) != 0;
     chunk_ = std::min(chunk, max_batch);
 
     int ch[5];
@@ -398,7 +423,9 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     View l21 = c2f(p, "model.21", cat20, nh, false, nullptr);
     named_["model.21"] = {l21};
 
-    // Detect
+    // Detect.  Its 3x3 convolutions produce the box-distribution logits directly: they stay f16 in the fp8 plan
+    // (RMR_FP8_HEAD=1 takes them along: 9 % of the FLOPs, measured to double the box error)
+    fp8_layer_ = std::getenv("RMR_FP8_HEAD") && atoi(std::getenv("RMR_FP8_HEAD")) != 0;
     const View feats[3] = {l15, l18, l21};
     const int strides[3] = {8, 16, 32};
     anchors_ = 0;
@@ -460,6 +487,10 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     }
     arena_.alloc(arena_halves_ * chunk_);
     arena32_.alloc(arena_floats_ * chunk_);
+    if (arena_bytes8_) {
+        if (arena_bytes8_ * chunk_ > kMaxViewBytes * 16) fail(RMR_ERR_CAPACITY, "fp8 plan: quantised activations do not fit");
+        arena8_.alloc(arena_bytes8_ * chunk_);
+    }
     input_.alloc((size_t)max_batch_ * H * W * 8);
     output_.alloc((size_t)max_batch_ * (4 + nc_) * anchors_);
     RMR_HIP(hipMemset(arena_.p, 0, arena_.n * sizeof(__half)));
@@ -477,7 +508,9 @@ void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     const int split = choice / 1000, c = choice % 1000;
     if ((a.in_slab_c || a.out_slab_c) && (c < 700 || c >= 800 || split))
         fail(RMR_ERR_LOGIC, "kernel %d cannot address planar channel groups", choice);
-    if (c >= 800) {
+    if (c >= 900) {
+        launch_conv_t32f8(ctx_, s, a, c - 900);
+    } else if (c >= 800) {
         launch_conv_t32(ctx_, s, a, c - 800);
     } else if (c >= 700) {
         launch_conv_pw(ctx_, s, a, c - 700);
@@ -508,7 +541,13 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     // one that samples the frames directly: the same arithmetic whichever way the input arrives
     if (conv_stem_supported(a)) return 500;
     std::vector<int> cands;
+    if (a.in8) {  // a layer of the fp8 plan: the e4m3 tiles and nothing else
+        for (int t = 0; t < conv_t32f8_num_tiles(); ++t)
+            if (conv_t32f8_supported(a, t)) cands.push_back(900 + t);
+        if (cands.empty()) fail(RMR_ERR_LOGIC, "fp8 plan: no e4m3 tile runs a layer with N = %d on %d-wide maps", a.Cout_pad, a.W);
+    }
     const bool slabbed = a.in_slab_c || a.out_slab_c;  // only conv_pw addresses planar channel groups
+    if (a.in8) goto timed;
     for (int t = 0; t < conv_num_tiles() && !slabbed; ++t)
         if (a.Cout_pad % conv_tile(t).bn == 0) cands.push_back(t);
     if (!slabbed && conv_dma_supported(a))
@@ -558,6 +597,7 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
             if (!only.empty()) cands.swap(only);
         }
     }
+timed:
     hipEvent_t e0, e1;
     RMR_HIP(hipEventCreate(&e0));
     RMR_HIP(hipEventCreate(&e1));
@@ -628,7 +668,7 @@ unsigned long long Yolov8::plan_signature() const {
     unsigned long long h = 1469598103934665603ull;
     const auto mix = [&](long long v) { h = (h ^ (unsigned long long)v) * 1099511628211ull; };
     for (const Op& op : ops_) {
-        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs);
+        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs), mix(op.fp8), mix(op.q_pitch);
         if (op.kind == OP_CONV) mix(convs_[op.conv].K), mix(convs_[op.conv].cout_pad);
     }
     return h;
@@ -646,6 +686,8 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
         return a.Cout_pad % ct.bn == 0 && conv_dma_splitk_tiles(a, c - 100) <= kSplitKMaxTiles &&
                conv_dma_splitk_ws_floats(a, c - 100, split) <= kSplitKWsFloats;
     }
+    if (a.in8) return !split && c >= 900 && c - 900 < conv_t32f8_num_tiles() && conv_t32f8_supported(a, c - 900);
+    if (c >= 900) return false;
     if (c >= 800) return c - 800 < conv_t32_num_tiles() && conv_t32_supported(a, c - 800);
     if (c >= 700) return c - 700 < conv_pw_num_variants() && conv_pw_supported(a, c - 700);
     if (slabbed) return false;  // only conv_pw addresses planar channel groups
@@ -766,6 +808,16 @@ ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
         a.wt_t32 = cw.w32.p;
         a.wt_t32_bytes = (unsigned)(cw.w32.n * sizeof(__half));
     }
+    if (op.fp8) {
+        const size_t q_bytes = (size_t)n * a.H * a.W * op.q_pitch;
+        if (q_bytes > kMaxViewBytes) fail(RMR_ERR_CAPACITY, "conv %d: the e4m3 input view exceeds 32-bit addressing", op.conv);
+        a.in8 = arena8_.p + op.q_off * chunk_;
+        a.in8_cs = op.q_pitch;
+        a.in8_bytes = (unsigned)q_bytes;
+        a.wt8 = cw.w8.p;
+        a.wt8_bytes = (unsigned)cw.w8.n;
+        a.wscale = cw.wscale.p;
+    }
     a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
     return a;
 }
@@ -803,6 +855,10 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
             launch_choice(s, a, it->second);
             break;
         }
+        case OP_QUANT:
+            launch_quant_f8(ctx_, s, hptr(op.in), op.in.cs, op.in.co, op.in.c, arena8_.p + op.q_off * chunk_, op.q_pitch,
+                            (long)n * op.in.h * op.in.w);
+            break;
         case OP_SPPF:
             launch_sppf_pools(ctx_, s, hptr(op.in), n, op.in.h, op.in.w, op.in.cs, op.in.co, op.in.c);
             break;

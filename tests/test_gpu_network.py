@@ -377,3 +377,49 @@ def test_pinned_plan_makes_an_image_independent_of_its_batch(rmr, packs, images,
     with pytest.raises(rmr.RmrError):
         rmr.Detector(packs[1], 12, (1920, 1080), 4).infer([images[0]] * 4)
     det.close()
+
+
+def test_fp8_plan_matches_its_oracle_and_stays_close_to_f16(rmr, packs, images):
+    """BASELINE configs[4]: RMR_PRECISION_FP8 -- the 3x3 / stride-1 layers with >= 64 input channels on e4m3
+    operands (conv_t32f8.hip), the rest f16.  Layer by layer the kernel is compared with PyTorch on identical
+    e4m3 operands (test_gpu_conv.py, 2e-3).  A whole network cannot be held to that: every e4m3 layer re-rounds
+    its input to 3 mantissa bits, so a last-bit difference in one layer's f16 output flips ~1 % of the next
+    layer's roundings by a whole ulp (6-12 % of the value) -- two exact implementations of the same fp8 plan
+    drift apart by about half of the quantisation error itself (tools/stage_errors.py 1 --fp8: 1.2 % of the
+    activations' rms after the first e4m3 C2f against 2.2 % between the fp8 and the f16 oracle).  So:
+      * the engine must be CLOSER to the fp8-emulating oracle than that oracle is to the f16 one, on the decoded
+        boxes and on the scores (an implementation error would not be);
+      * what the precision costs on this seeded random-weight network (the tolerance study; trained weights are
+        smoother): boxes 2.8 px on average, scores 4e-4 on average against the f16 oracle -- bars at 4.5 px / 2e-3;
+      * the confident detections of the f16 plan are still there."""
+    import oracle
+    from oracle import yolov8_ref as R
+    det = rmr.Detector(packs[1], 12, (1920, 1080), 3, precision="fp8")
+    got, _ = det.infer(images)
+    dets8 = det.detect(images)
+    det.close()
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    want8 = R.load(packs[1], fp8=True).forward(blobs)
+    want16 = R.load(packs[1], True).forward(blobs)
+    impl_b, impl_s = np.abs(got[:, :4] - want8[:, :4]).mean(), np.abs(got[:, 4:] - want8[:, 4:]).mean()
+    quant_b, quant_s = np.abs(want8[:, :4] - want16[:, :4]).mean(), np.abs(want8[:, 4:] - want16[:, 4:]).mean()
+    cost_b, cost_s = np.abs(got[:, :4] - want16[:, :4]).mean(), np.abs(got[:, 4:] - want16[:, 4:]).mean()
+    print(f"fp8 engine vs fp8 oracle: box {impl_b:.3f} px score {impl_s:.5f} | fp8 oracle vs f16 oracle: box {quant_b:.3f} px "
+          f"score {quant_s:.5f} | fp8 engine vs f16 oracle: box {cost_b:.3f} px (max {np.abs(got[:, :4] - want16[:, :4]).max():.1f}) score {cost_s:.5f}")
+    assert impl_b <= 1.1 * quant_b and impl_s <= 1.1 * quant_s
+    assert cost_b <= 4.5 and cost_s <= 2e-3
+    # the confident detections of the f16 plan survive: same label, IoU >= 0.8
+    f16 = rmr.Detector(packs[1], 12, (1920, 1080), 3)
+    ref, _ = f16.infer(images)
+    dets16 = f16.detect(images)
+    f16.close()
+    assert np.abs(got - ref).max() > 0.05      # and it is not the f16 plan under another name
+    kept = total = 0
+    for d8, d16 in zip(dets8, dets16):
+        for w in d16:
+            if w["confidence"] < 0.6:
+                continue
+            total += 1
+            kept += any(g["label"] == w["label"] and netutil.iou_xywh(tuple(g)[:4], tuple(w)[:4]) >= 0.8 for g in d8)
+    print(f"confident f16 detections kept by the fp8 plan: {kept} of {total}")
+    assert total == 0 or kept >= 0.5 * total

@@ -15,13 +15,14 @@ import rm_radar_amd as rmr  # noqa: E402
 from oracle import yolov8_ref as R  # noqa: E402
 
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+fp8 = "--fp8" in sys.argv
 images = [netutil.test_image(1), netutil.test_image(2, 810, 1080)]
 path = f"/tmp/stage_{nc}.rmrw"
 netutil.tuned_pack(path, nc, 11, 0.25, 0.01, images)
-det = rmr.Detector(path, nc, (1920, 1080), 2)
+det = rmr.Detector(path, nc, (1920, 1080), 2, precision="fp8" if fp8 else "f16")
 det.infer(images)
 blobs = np.stack([oracle.preprocess(im)[0] for im in images])
-f16 = R.load(path, True).features(blobs)
+f16 = R.load(path, True, fp8=fp8).features(blobs)
 f32 = R.load(path, False).features(blobs)
 print(f"{'stage':10s} {'shape':>16s} {'rms':>8s} | vs f16-emulating: {'max':>9s} {'mean':>9s} {'max/rms':>8s} | vs fp32: {'max':>9s} {'mean':>9s} | f16 vs fp32 oracle: {'max':>9s}")
 for name in f16:
