@@ -83,11 +83,15 @@ def parse():
     ap.add_argument("--gather", choices=("abi", "torch"), default="abi",
                     help="N > 1: the robot-record all-gather through the library's C-ABI communicator (rmr_comm_*, RCCL) "
                          "or through torch.distributed (RCCL as well)")
+    ap.add_argument("--dtype", choices=("f16", "fp8"), default="f16",
+                    help="fp8 = BASELINE configs[4]: e4m3 weights and activations in the 3x3 layers of backbone and neck")
     ap.add_argument("--config", type=int, default=2, help="BASELINE configs index: 2 = 640x640 + 30k points; 3 = one 1920x1080 "
                     "stream + 100k-point clouds per GPU")
     args = ap.parse_args()
     if args.config == 3:
         args.size, args.height, args.points = 1920, 1080, 100000
+    if args.config == 4:   # fp8-MFMA weights, batch = 256
+        args.dtype, args.batch = "fp8", 256
     return args
 
 
@@ -199,7 +203,7 @@ def main():
 
     B, K = args.batch, args.crops
     rdet = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1),
-                             device=local, max_frames=B)
+                             device=local, max_frames=B, precision=args.dtype)
     loc = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32),
                       device=local, max_frames=B)
     cap = rdet.max_cars
@@ -367,11 +371,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": "f16" if args.dtype == "f16" else "fp8 (e4m3 operands in the 3x3 layers of backbone and neck: ~61 % of the FLOPs; f16 elsewhere, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": f"{'configs[2]' if size == (640, 640) else 'configs[3]: one stream per GPU,'}: batch={B} synthetic {size[0]}x{size[1]} frames + "
+            "config": {"workload": f"{'configs[4]' if args.dtype == 'fp8' else 'configs[2]' if size == (640, 640) else 'configs[3]: one stream per GPU,'}: batch={B} synthetic {size[0]}x{size[1]} frames + "
                                    f"{args.points}-pt clouds per step per GPU, car YOLOv8m + {K} injected "
-                                   f"armor crops/frame (YOLOv8m, nc=12), seeded synthetic weights, f16 MFMA",
+                                   f"armor crops/frame (YOLOv8m, nc=12), seeded synthetic weights, {args.dtype} MFMA",
                        "frames_per_step_per_gpu": B, "crops_per_frame": K, "points_per_cloud": args.points,
                        "streams_per_gpu": 1, "gflop_per_frame": round(flops_frame / 1e9, 3)},
             "roofline": {"bound": "mfma", "kernel": "conv_* (the convolution launches of a step)", "achieved": round(ach, 2),
@@ -399,7 +403,8 @@ def main():
     if rank == 0 and not args.no_latency:
         rdet.close()
         loc.close()
-        r1 = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1), device=local)
+        r1 = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1), device=local,
+                               precision=args.dtype)
         l1 = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=local,
                          max_frames=1)
         lat = []

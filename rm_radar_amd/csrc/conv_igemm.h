@@ -49,6 +49,10 @@ struct ConvArgs {
     const unsigned char* wt8;
     unsigned wt8_bytes;
     const float* wscale;
+    // optional: the f16 output also as e4m3 rows of out8_cs bytes (the next e4m3 layer's input, written here
+    // instead of by a quantiser pass); bytes beyond Cout stay as they are (the planner keeps them zero)
+    unsigned char* out8;
+    int out8_cs;
     // split-K (conv_dma only): `split` workgroups share one output tile, each accumulating a
     // contiguous range of K slices; partial tiles meet in splitk_ws and the last arriver (ticket in
     // splitk_cnt, which it resets to 0) reduces them and runs the epilogue.  split <= 1: off.

@@ -393,7 +393,8 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
             // channels 8 gq + {0..3 | 4..7} and 8 gq + 8 + {0..3 | 4..7}: one v_permlane32_swap per dword
             // gives the lower lane all eight channels of group gq and the upper lane those of group gq + 1.
 #pragma unroll
-            for (int j = 0; j < NREP; ++j)
+            for (int j = 0; j < NREP; ++j) {
+                int q8[2] = {0, 0};   // the e4m3 bytes of group pair 0, until group pair 1 completes the 32-channel block
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     const int nb = n0 + (wn * NREP + j) * 32 + gp * 16;     // first channel of the pair of groups
@@ -450,12 +451,36 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
                         o.w[2] = s0[1];
                         o.w[3] = s1[1];
                     }
+                    if (a.out8) {
+                        // the same eight values once more as e4m3 (rounded from the f16 that is stored: what a
+                        // quantiser pass over the stored tensor would write).  Lane pair (l, l + 32) holds channels
+                        // [0..7 | 8..15] of the group pair gp = 0 and [16..23 | 24..31] of gp = 1: one more half
+                        // exchange gives the lower lane bytes 0..15 and the upper lane bytes 16..31 of the 32-channel
+                        // block -- one 16-byte store per lane and fragment instead of two of 8
+                        const auto sat = [](_Float16 v) { return __builtin_amdgcn_fmed3f((float)v, -448.f, 448.f); };
+                        int w0 = 0, w1 = 0;
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(o.h[0]), sat(o.h[1]), w0, false);
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(o.h[2]), sat(o.h[3]), w0, true);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(o.h[4]), sat(o.h[5]), w1, false);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(o.h[6]), sat(o.h[7]), w1, true);
+                        if (gp == 0) {
+                            q8[0] = w0, q8[1] = w1;
+                        } else {
+                            const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)q8[0], (unsigned)w0, false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)q8[1], (unsigned)w1, false, false);
+                            // lower lane: own gp 0 (0..7), the upper lane's gp 0 (8..15); upper lane: the lower lane's gp 1
+                            // (16..23), own gp 1 (24..31)
+                            const int4 q = kq ? make_int4((int)s0[0], (int)s1[0], w0, w1) : make_int4(q8[0], q8[1], (int)s0[1], (int)s1[1]);
+                            if (m < a.M) *(int4*)(a.out8 + (long)m * a.out8_cs + n0 + (wn * NREP + j) * 32 + kq * 16) = q;
+                        }
+                    }
                     if constexpr (EPI == 0) {
                         if (m < a.M) *(uint4*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + nl) = o.u;
                     } else {
                         *(uint4*)(smem + stg_base + fr * STG_PITCH + (j * 32 + gp * 16 + kq * 8) * 2) = o.u;
                     }
                 }
+            }
             if constexpr (EPI == 1) {
                 // the wave's 32 x (NREP * 32) block leaves as whole rows: NREP * 4 lanes per pixel
                 constexpr int CPP = NREP * 4;   // 16-byte chunks per pixel
@@ -567,6 +592,8 @@ void launch_conv_t32f8(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile)
     if (!conv_t32f8_supported(a, tile)) fail(RMR_ERR_LOGIC, "conv_t32f8: layer not supported by tile %d", tile);
     const T32F8Tile& t = kT32F8Tiles[tile];
     if (a.in8_cs % 64 || a.out_cs % 4 || a.out_co % 4) fail(RMR_ERR_LOGIC, "conv_t32f8: misaligned view");
+    if (a.out8 && (a.out32 || ((a.out_cs | a.out_co) & 7) || a.out8_cs % 16))
+        fail(RMR_ERR_LOGIC, "conv_t32f8: the e4m3 copy of the output needs an f16 output in 8-channel alignment");
     if (a.in8_bytes == 0 || a.in8_bytes > 0xf0000000ull || a.wt8_bytes == 0)
         fail(RMR_ERR_LOGIC, "conv_t32f8: buffer sizes not set or input view larger than 3.75 GiB");
     static std::once_flag once;

@@ -88,6 +88,10 @@ class Yolov8 {
         bool fp8 = false;
         size_t q_off = 0;
         int q_pitch = 0;
+        // OP_CONV of the fp8 plan whose output feeds another e4m3 layer: it writes that layer's input itself
+        bool q_out = false;
+        size_t q_out_off = 0;
+        int q_out_pitch = 0;
         int stride = 1, act = 1;
         // OP_HEAD
         View box, cls;

@@ -216,7 +216,24 @@ void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act
         q.q_off = arena_bytes8_;
         arena_bytes8_ += (size_t)in.h * in.w * q.q_pitch;
         arena_bytes8_ = (arena_bytes8_ + 255) & ~(size_t)255;
-        ops_.push_back(q);
+        // The e4m3 copy is written by a quantiser pass (read 2 B, write 1 B per value at ~3.9 TB/s: 2.1 ms of a
+        // 256-image forward).  RMR_FP8_FUSE=1: when the tensor comes out of an e4m3 layer, that layer's epilogue writes
+        // it instead -- measured a wash (26.2 vs 26.0 ms): the epilogue is store-issue bound, and its extra 16-byte
+        // stores over 32 pixel rows cost the 96-channel layers 18 % (901 -> 741 TFLOP/s), as much as the passes saved.
+        static const bool fuse = std::getenv("RMR_FP8_FUSE") && atoi(std::getenv("RMR_FP8_FUSE")) != 0;
+        Op* producer = nullptr;
+        for (auto it = ops_.rbegin(); it != ops_.rend() && fuse; ++it)
+            if (it->kind == OP_CONV && it->out.off == in.off && it->out.co == in.co && it->out.c == in.c && it->out.cs == in.cs) {
+                if (it->fp8 && !it->q_out && !it->out_f32 && ((it->out.cs | it->out.co) & 7) == 0) producer = &*it;
+                break;
+            }
+        if (producer) {
+            producer->q_out = true;
+            producer->q_out_off = q.q_off;
+            producer->q_out_pitch = q.q_pitch;
+        } else {
+            ops_.push_back(q);
+        }
         op.fp8 = true;
         op.q_off = q.q_off;
         op.q_pitch = q.q_pitch;
@@ -490,6 +507,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     if (arena_bytes8_) {
         if (arena_bytes8_ * chunk_ > kMaxViewBytes * 16) fail(RMR_ERR_CAPACITY, "fp8 plan: quantised activations do not fit");
         arena8_.alloc(arena_bytes8_ * chunk_);
+        RMR_HIP(hipMemset(arena8_.p, 0, arena8_.n));  // the bytes beyond a layer's channels stay zero for ever
     }
     input_.alloc((size_t)max_batch_ * H * W * 8);
     output_.alloc((size_t)max_batch_ * (4 + nc_) * anchors_);
@@ -668,7 +686,7 @@ unsigned long long Yolov8::plan_signature() const {
     unsigned long long h = 1469598103934665603ull;
     const auto mix = [&](long long v) { h = (h ^ (unsigned long long)v) * 1099511628211ull; };
     for (const Op& op : ops_) {
-        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs), mix(op.fp8), mix(op.q_pitch);
+        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs), mix(op.fp8), mix(op.q_pitch), mix(op.q_out);
         if (op.kind == OP_CONV) mix(convs_[op.conv].K), mix(convs_[op.conv].cout_pad);
     }
     return h;
@@ -817,6 +835,10 @@ ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
         a.wt8 = cw.w8.p;
         a.wt8_bytes = (unsigned)cw.w8.n;
         a.wscale = cw.wscale.p;
+        if (op.q_out) {
+            a.out8 = arena8_.p + op.q_out_off * chunk_;
+            a.out8_cs = op.q_out_pitch;
+        }
     }
     a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
     return a;
