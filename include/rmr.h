@@ -235,6 +235,9 @@ rmr_status rmr_detector_infer(rmr_detector* det, const rmr_image* imgs, const in
  * (dimensions only).  RMR_ERR_INVALID_ARGUMENT for an unknown stage.  TensorRT offers the same through
  * marked network outputs (detector.cpp:187-231 builds the network from the ONNX graph). */
 rmr_status rmr_detector_read_feature(rmr_detector* det, const char* name, int img, float* out, int* dims);
+/* bytes of activation memory the detector holds on its GPU (sized for rmr_detector_chunk images per launch) */
+double rmr_detector_arena_bytes(const rmr_detector* det);
+int rmr_detector_chunk(const rmr_detector* det);
 int rmr_detector_anchors(const rmr_detector* det);
 int rmr_detector_channels(const rmr_detector* det);
 /* algorithmic FLOPs of one 640x640 forward (2*MAC over all convs) */

@@ -315,6 +315,13 @@ class Detector:
         res = [out[i, :counts[i]].copy() for i in range(n)]
         return res[0] if single else res
 
+    def arena_bytes(self) -> float:
+        """Activation memory held on the GPU (for `chunk()` images per launch)."""
+        return lib().rmr_detector_arena_bytes(self._h)
+
+    def chunk(self) -> int:
+        return lib().rmr_detector_chunk(self._h)
+
     def read_feature(self, name, img=0):
         """Output of backbone / neck stage `name` ("model.0" ... "model.21") for image `img` of the last call,
         f32 [h, w, c] (parity hook)."""

@@ -146,6 +146,8 @@ SYMBOLS = {
     "rmr_detector_detect": (C.c_int, [_vp, _P(Image), _ip, C.c_int, _vp, _ip, C.c_int]),
     "rmr_detector_infer": (C.c_int, [_vp, _P(Image), _ip, C.c_int, _fp, _P(PreParam)]),
     "rmr_detector_read_feature": (C.c_int, [_vp, C.c_char_p, C.c_int, _fp, _ip]),
+    "rmr_detector_arena_bytes": (C.c_double, [_vp]),
+    "rmr_detector_chunk": (C.c_int, [_vp]),
     "rmr_detector_anchors": (C.c_int, [_vp]),
     "rmr_detector_channels": (C.c_int, [_vp]),
     "rmr_detector_flops_per_image": (C.c_double, [_vp]),

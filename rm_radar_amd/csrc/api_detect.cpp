@@ -57,6 +57,8 @@ rmr_status rmr_detector_read_feature(rmr_detector* det, const char* name, int im
     });
 }
 
+double rmr_detector_arena_bytes(const rmr_detector* det) { return det ? (double)const_cast<rmr_detector*>(det)->impl.net().arena_bytes() : 0.0; }
+int rmr_detector_chunk(const rmr_detector* det) { return det ? const_cast<rmr_detector*>(det)->impl.net().chunk() : 0; }
 int rmr_detector_anchors(const rmr_detector* det) { return det ? const_cast<rmr_detector*>(det)->impl.net().anchors() : 0; }
 int rmr_detector_channels(const rmr_detector* det) { return det ? const_cast<rmr_detector*>(det)->impl.net().channels() : 0; }
 double rmr_detector_flops_per_image(const rmr_detector* det) {

@@ -46,9 +46,12 @@ class Yolov8 {
     int channels() const { return 4 + nc_; }
     double flops_per_image() const { return flops_; }
     int max_batch() const { return max_batch_; }
+    // bytes of activation memory (all arenas, all images of a chunk) and images per chunk
+    size_t arena_bytes() const { return arena_.n * sizeof(__half) + arena32_.n * sizeof(float) + arena8_.n; }
+    int chunk() const { return chunk_; }
     // Debug / parity hook: the output of a backbone / neck stage ("model.0" ... "model.21") of image `img` of
-    // the last forward(), as f32 [h][w][c] on the host (out = nullptr: the dimensions only).  The arena never
-    // reuses memory, so every stage output is still there after a forward.
+    // the last forward(), as f32 [h][w][c] on the host (out = nullptr: the dimensions only).  Needs a detector
+    // created with RMR_ARENA_REUSE=0 (otherwise later layers have overwritten the stage outputs).
     bool read_feature(hipStream_t s, const std::string& name, int img, float* out, int dims[3]);
 
     // network input: f16 NHWC with 8 channels per pixel (RGB + 5 zero lanes), [max_batch]
@@ -99,6 +102,19 @@ class Yolov8 {
     };
 
     View alloc(int h, int w, int c, bool f32 = false);
+    // Plan-time liveness: every buffer lives from the first to the last op that touches it; buffers whose
+    // lifetimes do not meet share arena memory (27 GiB -> a few GiB for a 256-image armor detector).
+    // RMR_ARENA_REUSE=0 keeps one region per buffer, which the stage-output hook (read_feature) needs.
+    void compact_arenas();
+    struct Alloc {
+        size_t off, size;  // per image, in elements of its arena
+        int arena;         // 0 f16, 1 f32, 2 e4m3
+        int group;         // allocations of one group keep their relative placement (slabs)
+    };
+    std::vector<Alloc> allocs_;
+    int alloc_group_ = 0;   // != 0 while a group is being allocated
+    int next_group_ = 1;
+    bool arena_reuse_ = true;
     static View slice(const View& v, int co, int c);
     // ci0 / ci_n: the slice of input channels to keep (ci_n = 0: all); no_bias: a zero bias
     int add_conv_weights(const WeightPack& p, const std::string& name, int cin_pad, int ci0 = 0, int ci_n = 0,

@@ -95,6 +95,7 @@ View Yolov8::alloc(int h, int w, int c, bool f32) {
     v.off = top;
     top += (size_t)h * w * c;
     top = (top + 63) & ~(size_t)63;
+    allocs_.push_back(Alloc{v.off, top - v.off, f32 ? 1 : 0, alloc_group_});
     return v;
 }
 
@@ -216,6 +217,7 @@ void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act
         q.q_off = arena_bytes8_;
         arena_bytes8_ += (size_t)in.h * in.w * q.q_pitch;
         arena_bytes8_ = (arena_bytes8_ + 255) & ~(size_t)255;
+        allocs_.push_back(Alloc{q.q_off, arena_bytes8_ - q.q_off, 2, 0});
         // The e4m3 copy is written by a quantiser pass (read 2 B, write 1 B per value at ~3.9 TB/s: 2.1 ms of a
         // 256-image forward).  RMR_FP8_FUSE=1: when the tensor comes out of an e4m3 layer, that layer's epilogue writes
         // it instead -- measured a wash (26.2 vs 26.0 ms): the epilogue is store-issue bound, and its extra 16-byte
@@ -270,11 +272,13 @@ View Yolov8::c2f(const WeightPack& p, const std::string& name, const View& x, in
     std::vector<View> chunk(2 + n);
     View cat{};
     if (slab) {
+        alloc_group_ = next_group_++;   // the slabs keep their equal spacing when the arena is compacted
         for (int i = 0; i < 2 + n; ++i) {
             chunk[i] = alloc(x.h, x.w, c);
             if (i && chunk[i].off - chunk[i - 1].off != chunk[1].off - chunk[0].off)
                 fail(RMR_ERR_LOGIC, "planner: slabs are not equally spaced");
         }
+        alloc_group_ = 0;
     } else {
         cat = alloc(x.h, x.w, (2 + n) * c);
         for (int i = 0; i < 2 + n; ++i) chunk[i] = slice(cat, i * c, c);
@@ -315,6 +319,113 @@ View Yolov8::c2f(const WeightPack& p, const std::string& name, const View& x, in
         ops_.back().in_slab_step = step;
     }
     return out;
+}
+
+void Yolov8::compact_arenas() {
+    // merge the allocations of a group into one block (their relative placement is part of the plan)
+    struct Block {
+        size_t off, size;
+        int arena;
+        int first = 1 << 30, last = -1;
+        size_t new_off = 0;
+    };
+    std::vector<Block> blocks;
+    for (const Alloc& a : allocs_) {
+        if (a.group && !blocks.empty() && blocks.back().arena == a.arena && blocks.back().off + blocks.back().size == a.off &&
+            &a != &allocs_.front() && (&a)[-1].group == a.group) {
+            blocks.back().size += a.size;
+            continue;
+        }
+        blocks.push_back(Block{a.off, a.size, a.arena});
+    }
+    const auto block_of = [&](int arena, size_t off) -> Block* {
+        for (Block& b : blocks)
+            if (b.arena == arena && off >= b.off && off < b.off + b.size) return &b;
+        return nullptr;
+    };
+    const auto touch = [&](int arena, size_t off, int i) {
+        if (Block* b = block_of(arena, off)) b->first = std::min(b->first, i), b->last = std::max(b->last, i);
+    };
+    // lifetimes: the ops run in order on one stream
+    for (int i = 0; i < (int)ops_.size(); ++i) {
+        const Op& op = ops_[i];
+        const auto view = [&](const View& v, bool f32) {
+            if (v.c || v.cs) touch(f32 ? 1 : 0, v.off, i);
+        };
+        switch (op.kind) {
+            case OP_CONV:
+                if (!op.in_is_input) view(op.in, false);
+                view(op.out, op.out_f32);
+                view(op.res, false);
+                view(op.pre, true);
+                if (op.fp8) touch(2, op.q_off, i);
+                if (op.q_out) touch(2, op.q_out_off, i);
+                // planar channel groups: the view names the first slab, the op touches all of them
+                if (op.in_slab_c)
+                    for (int k = 1; k < op.in.c / op.in_slab_c; ++k) touch(0, op.in.off + k * op.in_slab_step, i);
+                if (op.out_slab_c)
+                    for (int k = 1; k < op.out.c / op.out_slab_c; ++k) touch(0, op.out.off + k * op.out_slab_step, i);
+                break;
+            case OP_QUANT:
+                view(op.in, false);
+                touch(2, op.q_off, i);
+                break;
+            case OP_SPPF:
+                view(op.in, false);
+                break;
+            case OP_UP:
+                view(op.in, false);
+                view(op.out, false);
+                break;
+            case OP_HEAD:
+                view(op.box, true);
+                view(op.cls, true);
+                break;
+        }
+    }
+    // first fit in order of first use: a block may take the memory of blocks that died before it is born
+    size_t top[3] = {0, 0, 0};
+    std::vector<Block*> order;
+    for (Block& b : blocks)
+        if (b.last >= 0) order.push_back(&b);
+    std::stable_sort(order.begin(), order.end(), [](const Block* a, const Block* b) { return a->first < b->first; });
+    std::vector<Block*> placed;
+    for (Block* b : order) {
+        size_t pos = 0;
+        for (bool moved = true; moved;) {
+            moved = false;
+            for (const Block* o : placed)
+                if (o->arena == b->arena && !(o->last < b->first || b->last < o->first) && pos < o->new_off + o->size &&
+                    o->new_off < pos + b->size) {
+                    pos = o->new_off + o->size;
+                    moved = true;
+                }
+        }
+        b->new_off = pos;
+        top[b->arena] = std::max(top[b->arena], pos + b->size);
+        placed.push_back(b);
+    }
+    // move every view
+    const auto move = [&](View& v, bool f32) {
+        if (!(v.c || v.cs)) return;
+        if (const Block* b = block_of(f32 ? 1 : 0, v.off)) v.off = b->new_off + (v.off - b->off);
+    };
+    const auto move8 = [&](size_t& off) {
+        if (const Block* b = block_of(2, off)) off = b->new_off + (off - b->off);
+    };
+    for (Op& op : ops_) {
+        const bool out32 = op.kind == OP_CONV && op.out_f32;
+        if (!(op.kind == OP_CONV && op.in_is_input)) move(op.in, false);
+        move(op.out, out32);
+        move(op.res, false);
+        move(op.pre, true);
+        move(op.box, true);
+        move(op.cls, true);
+        if (op.fp8 || op.kind == OP_QUANT) move8(op.q_off);
+        if (op.q_out) move8(op.q_out_off);
+    }
+    for (auto& kv : named_) move(kv.second.v, false);
+    arena_halves_ = top[0], arena_floats_ = top[1], arena_bytes8_ = top[2];
 }
 
 // whether conv_pw has a variant for a 1x1 layer of this shape (the planner's slab decision)
@@ -473,6 +584,8 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
         a_off += f.h * f.w;
     }
 
+    if (const char* e = std::getenv("RMR_ARENA_REUSE")) arena_reuse_ = atoi(e) != 0;
+    if (arena_reuse_) compact_arenas();
     // Images per launch: every activation view (pixels x its buffer's channel pitch, plus the span of its
     // slabs) must stay below the 32-bit offset range of the kernels' buffer resources.  256 images of a
     // 640 x 640 network are far below it; a 1920 x 1088 network is not.
@@ -903,6 +1016,9 @@ bool Yolov8::read_feature(hipStream_t s, const std::string& name, int img, float
     dims[0] = v.h, dims[1] = v.w, dims[2] = v.c;
     if (!out) return true;
     if (img < 0 || img >= chunk_) fail(RMR_ERR_INVALID_ARGUMENT, "read_feature: image %d is outside the last chunk", img);
+    if (arena_reuse_)
+        fail(RMR_ERR_LOGIC, "read_feature: stage outputs are overwritten by later layers when the arena is compacted; "
+                            "create the detector with RMR_ARENA_REUSE=0 in the environment");
     // stage outputs are interleaved NHWC views (pixel pitch cs, first channel co)
     const size_t px = (size_t)v.h * v.w;
     std::vector<__half> host(px * v.cs);

@@ -334,10 +334,11 @@ STAGE_BUDGET = {"model.0": 2e-5, "model.1": 2e-5, "model.2": 4e-4, "model.3": 6e
                 "model.12": 1.7e-3, "model.15": 1.9e-3, "model.18": 2.2e-3, "model.21": 2.0e-3}
 
 
-def test_stage_error_budget(rmr, packs, images):
+def test_stage_error_budget(rmr, packs, images, monkeypatch):
     """Every backbone / neck stage output against the f16-emulating oracle: the error budget layer by layer
     (the head tolerance of the other tests is the end of this table, not an assumption)."""
     import oracle
+    monkeypatch.setenv("RMR_ARENA_REUSE", "0")   # keep every stage output until it is read
     from oracle import yolov8_ref as R
     det = rmr.Detector(packs[0], 1, (1920, 1080), 2)
     det.infer(images[:2])

@@ -4,6 +4,8 @@ tests/test_gpu_network.py::test_stage_error_budget is set from).  usage: stage_e
 import os
 import sys
 
+os.environ["RMR_ARENA_REUSE"] = "0"  # stage outputs must survive the forward
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
