@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--gather", choices=("abi", "torch"), default="abi",
                     help="N > 1: the robot-record all-gather through the library's C-ABI communicator (rmr_comm_*, RCCL) "
                          "or through torch.distributed (RCCL as well)")
+    ap.add_argument("--streams", type=int, default=1, help="camera / LiDAR streams per GPU: the batch divides into this many "
+                    "streams, each with its own Locator state (background image + depth ring in HBM), one detector batch over all")
     ap.add_argument("--dtype", choices=("f16", "fp8"), default="f16",
                     help="fp8 = BASELINE configs[4]: e4m3 weights and activations in the 3x3 layers of backbone and neck")
     ap.add_argument("--config", type=int, default=2, help="BASELINE configs index: 2 = 640x640 + 30k points; 3 = one 1920x1080 "
@@ -204,9 +206,14 @@ def main():
     B, K = args.batch, args.crops
     rdet = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1),
                              device=local, max_frames=B, precision=args.dtype)
-    loc = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32),
-                      device=local, max_frames=B)
+    S = max(1, args.streams)
+    if B % S:
+        raise SystemExit(f"--batch {B} does not divide into --streams {S}")
+    locs = [rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32),
+                        device=local, max_frames=B // S) for _ in range(S)]
+    loc = locs[0] if S == 1 else locs
     cap = rdet.max_cars
+    arena_gib = rdet.arena_bytes() / 2 ** 30
     flops_frame = W.flops_per_image("m", 1) + K * W.flops_per_image("m", 12)
 
     import ctypes as C
@@ -377,7 +384,8 @@ def main():
                                    f"{args.points}-pt clouds per step per GPU, car YOLOv8m + {K} injected "
                                    f"armor crops/frame (YOLOv8m, nc=12), seeded synthetic weights, {args.dtype} MFMA",
                        "frames_per_step_per_gpu": B, "crops_per_frame": K, "points_per_cloud": args.points,
-                       "streams_per_gpu": 1, "gflop_per_frame": round(flops_frame / 1e9, 3)},
+                       "streams_per_gpu": S, "gflop_per_frame": round(flops_frame / 1e9, 3),
+                       "activation_arena_gib": round(arena_gib, 2)},
             "roofline": {"bound": "mfma", "kernel": "conv_* (the convolution launches of a step)", "achieved": round(ach, 2),
                          "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / F16_DENSE_PEAK_TFLOPS, 4),
@@ -402,7 +410,8 @@ def main():
     # ---- batch-1 latency (p50), host inputs: H2D inside the timed region ----
     if rank == 0 and not args.no_latency:
         rdet.close()
-        loc.close()
+        for l in locs:
+            l.close()
         r1 = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=max(K, 1), opt_cars=max(K, 1), device=local,
                                precision=args.dtype)
         l1 = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=local,

@@ -264,6 +264,8 @@ typedef struct {
 } rmr_robot_detector_cfg;
 
 void rmr_robot_detector_cfg_default(rmr_robot_detector_cfg* cfg);
+/* bytes of activation memory both networks hold on the GPU */
+double rmr_robot_detector_arena_bytes(rmr_robot_detector* rd);
 rmr_status rmr_robot_detector_create(const rmr_robot_detector_cfg* cfg, rmr_robot_detector** out);
 void rmr_robot_detector_destroy(rmr_robot_detector* rd);
 /* RobotDetector::detect (detector.cpp:413-455): one frame -> robots (cap entries) */
@@ -357,6 +359,15 @@ rmr_status rmr_pipeline_run_batch(rmr_robot_detector* rd, rmr_locator* loc, cons
                                   const float* const* clouds, const int* n_points, int stride_bytes,
                                   int mem, int n_frames, const int* forced_crops, int forced_per_frame,
                                   rmr_robot* out, int* n_out, int cap);
+/* The same for n_streams camera / LiDAR streams that share this GPU: one detector batch over all n_frames frames
+ * (stream-major: stream s owns frames [s * n_frames / n_streams, ...)), one Locator per stream (locs[n_streams],
+ * each created with max_frames >= n_frames / n_streams), their locate work on one helper thread and HIP stream
+ * each.  State per stream in HBM: (8 + 4 (queue + 2)) bytes per zoomed pixel -- 2.9 MB at 640 x 640, so the
+ * 288 GB of a GPU bound the number of streams only through the detector's batch. */
+rmr_status rmr_pipeline_run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_streams,
+                                    const rmr_image* imgs, const float* const* clouds, const int* n_points,
+                                    int stride_bytes, int mem, int n_frames, const int* forced_crops,
+                                    int forced_per_frame, rmr_robot* out, int* n_out, int cap);
 
 /* ---------------------------------------------------------------- per-kernel profile */
 

@@ -377,6 +377,10 @@ class RobotDetector:
 
     __del__ = close
 
+    def arena_bytes(self) -> float:
+        """Activation memory both networks hold on the GPU."""
+        return lib().rmr_robot_detector_arena_bytes(self._h)
+
     def detect(self, image) -> List[Robot]:
         """RobotDetector::detect(const cv::Mat&) (detector.cpp:413-455)"""
         keep: list = []
@@ -612,9 +616,10 @@ class FrameBatch:
         self._out = None  # (cap, Robot array, counts): reused from call to call
 
 
-def run_batch(robot_detector: "RobotDetector", locator: "Locator", images, clouds=None, forced_crops=None):
+def run_batch(robot_detector: "RobotDetector", locator, images, clouds=None, forced_crops=None):
     """Throughput mode of SampleRadar::runOnce (sample_radar.h:106-127) over the frames of ONE
-    stream in one native call: update + cluster of every cloud on a helper thread while the
+    stream -- or, with a list of Locators, of len(locator) streams sharing this GPU and its detector (frames
+    stream-major, the same number per stream) -- in one native call: update + cluster of every cloud on a helper thread while the
     two-stage detect runs, then one batched search.  `images` / `clouds`: lists (see FrameBatch), or
     a FrameBatch built once for buffers that are refilled in place (then the returned arrays are
     reused by the next call with that batch too).  Returns (ctypes Robot array [n_frames * max_cars],
@@ -635,6 +640,12 @@ def run_batch(robot_detector: "RobotDetector", locator: "Locator", images, cloud
             forced_crops.ndim == 3 and forced_crops.flags.c_contiguous else \
             np.ascontiguousarray(np.asarray(forced_crops, np.int32).reshape(n, -1, 4))
         per = fc.shape[1]
+    if isinstance(locator, (list, tuple)):
+        handles = (C.c_void_p * len(locator))(*[l._h for l in locator])
+        check(lib().rmr_pipeline_run_streams(robot_detector._h, handles, len(locator), fb.images, fb.ptrs, _lib.ip(fb.npts),
+                                             fb.stride, _lib.MEM_DEVICE if fb.device else _lib.MEM_HOST, n,
+                                             _lib.ip(fc) if fc is not None else None, per, out, _lib.ip(counts), cap))
+        return out, counts
     check(lib().rmr_pipeline_run_batch(robot_detector._h, locator._h, fb.images, fb.ptrs, _lib.ip(fb.npts), fb.stride,
                                        _lib.MEM_DEVICE if fb.device else _lib.MEM_HOST, n,
                                        _lib.ip(fc) if fc is not None else None, per, out, _lib.ip(counts), cap))

@@ -147,6 +147,7 @@ SYMBOLS = {
     "rmr_detector_infer": (C.c_int, [_vp, _P(Image), _ip, C.c_int, _fp, _P(PreParam)]),
     "rmr_detector_read_feature": (C.c_int, [_vp, C.c_char_p, C.c_int, _fp, _ip]),
     "rmr_detector_arena_bytes": (C.c_double, [_vp]),
+    "rmr_robot_detector_arena_bytes": (C.c_double, [_vp]),
     "rmr_detector_chunk": (C.c_int, [_vp]),
     "rmr_detector_anchors": (C.c_int, [_vp]),
     "rmr_detector_channels": (C.c_int, [_vp]),
@@ -182,6 +183,8 @@ SYMBOLS = {
     "rmr_locator_num_clusters": (C.c_int, [_vp]),
     "rmr_pipeline_run_batch": (C.c_int, [_vp, _vp, _P(Image), _P(_fp), _ip, C.c_int, C.c_int, C.c_int, _ip, C.c_int,
                                          _P(Robot), _ip, C.c_int]),
+    "rmr_pipeline_run_streams": (C.c_int, [_vp, _P(_vp), C.c_int, _P(Image), _P(_fp), _ip, C.c_int, C.c_int, C.c_int, _ip,
+                                           C.c_int, _P(Robot), _ip, C.c_int]),
     "rmr_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "rmr_profile_reset": (C.c_int, [C.c_int]),
     "rmr_profile_read": (C.c_int, [C.c_int, _P(KernelStat), C.c_int, _ip]),

@@ -90,6 +90,7 @@ rmr_status rmr_robot_detector_create(const rmr_robot_detector_cfg* cfg, rmr_robo
 }
 
 void rmr_robot_detector_destroy(rmr_robot_detector* rd) { delete rd; }
+double rmr_robot_detector_arena_bytes(rmr_robot_detector* rd) { return rd ? (double)rd->impl.arena_bytes() : 0.0; }
 
 rmr_status rmr_robot_detector_detect(rmr_robot_detector* rd, const rmr_image* img, rmr_robot* out, int* n_out,
                                      int cap) {

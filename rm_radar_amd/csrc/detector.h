@@ -68,6 +68,7 @@ class Detector {
 class RobotDetector {
    public:
     explicit RobotDetector(const rmr_robot_detector_cfg& cfg);
+    size_t arena_bytes() { return car_->net().arena_bytes() + armor_->net().arena_bytes(); }
     // RobotDetector::detect (detector.cpp:413-455), batched over frames
     // after_cars (optional) runs as soon as stage 1 is known -- the car boxes per frame, before the
     // armor stage is enqueued; car_index_out (optional, [n_frames][cap]) names the car each output

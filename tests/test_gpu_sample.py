@@ -192,3 +192,55 @@ def test_rccl_communicator_through_the_c_abi_one_rank():
         got = comm.all_gather_records(block)
         assert got.shape == (1, 4, 3, rd.RECORD_WORDS) and np.array_equal(got[0], block)
     comm.close()
+
+
+def test_streams_sharing_a_gpu_equal_their_separate_runs(tmp_path_factory):
+    """rmr_pipeline_run_streams: two camera / LiDAR streams on one GPU -- one detector batch over the frames of
+    both, one Locator (background image + depth ring) per stream -- return what each stream returns when it runs
+    through rmr_pipeline_run_batch on its own."""
+    import rm_radar_amd as rmr
+    from rm_radar_amd import weights as W
+    d = tmp_path_factory.mktemp("st_packs")
+    car, armor = str(d / "car.rmrw"), str(d / "armor.rmrw")
+    W.make_synthetic_pack(car, "m", 1, seed=1, cls_bias=-6.0)
+    W.make_synthetic_pack(armor, "m", 12, seed=2, cls_bias=-3.0)
+    S, per, k, size = 2, 2, 2, (640, 640)
+    rng = np.random.default_rng(11)
+    rects = [[(100 + 40 * s, 300, 120, 90), (400, 200 - 30 * s, 80, 120)] for s in range(S) for _ in range(per)]
+    images = [scenes.synthetic_image(90 + f) for f in range(S * per)]
+    bgs = [scenes.make_cloud(rng, 30000, scenes.K640, scenes.SAMPLE_L2C, size) for _ in range(S)]
+    clouds = [scenes.make_cloud(rng, 20000, scenes.K640, scenes.SAMPLE_L2C, size, [(r, 2000.0, 250) for r in rects[f]])
+              for f in range(S * per)]
+    rd = rmr.RobotDetector(car, armor, size, 12, max_cars=k, opt_cars=k, max_frames=S * per)
+    cap = rd.max_cars
+    eye = np.eye(4, dtype=np.float32)
+
+    def fresh():
+        ls = [rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, eye, max_frames=per) for _ in range(S)]
+        for l, bg in zip(ls, bgs):
+            l.update(bg)
+        return ls
+
+    locs = fresh()
+    robots, counts = rmr.run_batch(rd, locs, images, clouds, rects)
+    together = [[rmr.Robot.from_c(robots[f * cap + i]) for i in range(counts[f])] for f in range(S * per)]
+    for l in locs:
+        l.close()
+    locs = fresh()
+    apart = []
+    for s in range(S):
+        sl = slice(s * per, (s + 1) * per)
+        r2, c2 = rmr.run_batch(rd, locs[s], images[sl], clouds[sl], rects[sl])
+        apart += [[rmr.Robot.from_c(r2[f * cap + i]) for i in range(c2[f])] for f in range(per)]
+    located = 0
+    for a, b in zip(together, apart):
+        assert len(a) == len(b) >= 1
+        for x, y in zip(a, b):
+            assert (x.rect, x.label, x.location) == (y.rect, y.label, y.location)
+            located += x.location is not None
+    assert located >= 2
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.run_batch(rd, locs, images[:3], clouds[:3], rects[:3])   # 3 frames do not divide into 2 streams
+    for l in locs:
+        l.close()
+    rd.close()
