@@ -284,16 +284,19 @@ __device__ void cc_block(int n, const float* __restrict__ xyz, float tol2, int m
                          const float* lxyz, int* nvalid, int* __restrict__ fg_cluster, const int* pix,
                          const float* __restrict__ depth, float row_k, int wz) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += CC_THREADS) {
-        parent[i] = i;
-        csize[i] = 0;
-        root_id[i] = -1;
+    if (SMALL) {
+        for (int i = tid; i < n; i += CC_THREADS) {
+            parent[i] = i;
+            csize[i] = 0;
+            root_id[i] = -1;
+        }
     }
     if (tid == 0) *nvalid = 0;
     __syncthreads();
-    // all pairs j < i; thread-strided i keeps the triangular work balanced across threads
+    // all pairs j < i; thread-strided i keeps the triangular work balanced across threads.  (Lists beyond the
+    // LDS forest arrive here with the forest already built by cc_init_grid / cc_pairs_grid over the whole chip.)
     const float* src = SMALL ? lxyz : xyz;
-    for (int i = tid; i < n; i += CC_THREADS) {
+    for (int i = tid; i < (SMALL ? n : 0); i += CC_THREADS) {
         const float ax = src[i * 3 + 0], ay = src[i * 3 + 1], az = src[i * 3 + 2];
         int my_root = i;
         int j0 = 0;
@@ -361,6 +364,67 @@ __device__ void cc_block(int n, const float* __restrict__ xyz, float tol2, int m
     }
     __syncthreads();
     for (int i = tid; i < n; i += CC_THREADS) fg_cluster[i] = root_id[cc_find<SMALL>(parent, i)];
+}
+
+// ---- lists beyond CC_LDS_MAX points (K = 20 robots of ~400 points): the pair phase over the whole chip ----------
+// One workgroup cannot hide 8 k points x a few hundred candidates each (0.2 ms per frame); the union-find forest
+// moves to global memory (L2 atomics: compare-and-swap hooks the larger root under the smaller, as in the LDS
+// forest, so the partition and its roots = lowest member index are the same) and the points spread over the
+// grid.  Both kernels return at once for a list that fits the single-workgroup path.
+__global__ __launch_bounds__(256) void cc_init_grid(const int* __restrict__ counters, int* parent, int* csize, int* root_id) {
+    const int n = counters[0];
+    if (n <= CC_LDS_MAX) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) parent[i] = i, csize[i] = 0, root_id[i] = -1;
+}
+
+__global__ __launch_bounds__(256) void cc_pairs_grid(const int* __restrict__ counters, const float* __restrict__ xyz, float tol2,
+                                                      int* parent_g, const int* __restrict__ pix,
+                                                      const float* __restrict__ depth, float row_k, int wz) {
+    const int n = counters[0];
+    if (n <= CC_LDS_MAX) return;
+    volatile int* parent = parent_g;
+    // a wave takes one point and spreads its candidates over the lanes: neighbouring points have neighbouring
+    // candidate ranges, so the wave's loads are the same few cache lines
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+    for (int i = wave; i < n; i += n_waves) {
+        const float ax = xyz[i * 3 + 0], ay = xyz[i * 3 + 1], az = xyz[i * 3 + 2];
+        int j0 = 0;
+        const float d_i = depth[i];
+        if (row_k > 0.f && d_i > 0.f) {
+            const float rows = row_k / d_i;
+            if (rows < 1.0e6f) {
+                const int v_lo = pix[i] / wz - ((int)rows + 1);
+                if (v_lo > 0) {
+                    const int key = v_lo * wz;
+                    int lo = 0, hi = i;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (pix[mid] < key) lo = mid + 1; else hi = mid;
+                    }
+                    j0 = lo;
+                }
+            }
+        }
+        for (int j = j0 + lane; j < i; j += 64) {
+            const float dx = xyz[j * 3 + 0] - ax, dy = xyz[j * 3 + 1] - ay, dz = xyz[j * 3 + 2] - az;
+            if (dx * dx + dy * dy + dz * dz < tol2) {
+                int a = i, b = j;
+                for (;;) {
+                    a = cc_find<false>(parent, a);
+                    b = cc_find<false>(parent, b);
+                    if (a == b) break;
+                    if (a < b) {
+                        const int t = a;
+                        a = b;
+                        b = t;
+                    }
+                    if (atomicCAS((int*)parent + a, a, b) == a) break;
+                }
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(CC_THREADS) void cc_fused(int* __restrict__ counters, const float* __restrict__ xyz,
@@ -775,7 +839,6 @@ void Locator::cluster() {
     std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)cc_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * CC_LDS_MAX * 4);
     });
-    (void)gfg;
     // rows two points closer than the tolerance can be apart, times the depth (see cc_block);
     // only for a pinhole intrinsic whose image row depends on y alone
     float row_k = 0.f;
@@ -784,6 +847,11 @@ void Locator::cluster() {
         const float fy = prm_.K[4], cy = prm_.K[5], h_full = (float)prm_.hz / prm_.zoom;
         const float t_max = std::max(std::fabs(cy), std::fabs(h_full - cy)) / fy;
         row_k = (float)(prm_.zoom * fy * std::sqrt(prm_.tol2) / s_min * (1.f + t_max) * 1.001);
+    }
+    if (mf > CC_LDS_MAX) {   // lists that can outgrow the single-workgroup forest: pair phase over the chip
+        cc_init_grid<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p, root_id_.p);
+        cc_pairs_grid<<<std::min(gfg * 4, 4 * ctx_.num_cus), 256, 0, stream_>>>(counters_.p, cur.fg_xyz, prm_.tol2, parent_.p, cur.fg_pixel,
+                                                                             fg_depth_.p, row_k, prm_.wz);
     }
     cc_fused<<<1, CC_THREADS, 9 * CC_LDS_MAX * sizeof(int), stream_>>>(
         counters_.p, cur.fg_xyz, prm_.tol2, prm_.min_cluster, prm_.max_cluster, parent_.p, csize_.p, root_id_.p,

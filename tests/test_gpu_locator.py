@@ -283,3 +283,26 @@ def test_search_batch_equals_per_frame_search(rmr):
     assert located >= 4
     with pytest.raises(rmr.InvalidArgument):
         loc.search_batch_raw(a, np.array([cap + 1] * nf, np.int32), cap)
+
+
+def test_dense_foreground_beyond_one_workgroup(rmr, oracle):
+    """K = 20 robots of ~600 points (kMaxBatchSize cars, sample_radar.h:34): more than 4096 foreground points,
+    so the pair phase of the clustering runs over the whole chip on a global union-find forest (cc_init_grid /
+    cc_pairs_grid) instead of inside the single-workgroup kernel.  Same foreground list, partition and cluster
+    ids as the oracle (the PCL Euclidean clustering of locate.cpp:255-257)."""
+    size = (1280, 1024)
+    K = np.array([[832, 0, 640], [0, 832, 512], [0, 0, 1]], np.float32)
+    rng = np.random.default_rng(21)
+    gpu, cpu = _pair(rmr, oracle, size, K, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), max_cluster_size=4000)
+    for _ in range(2):   # warm the background image and the depth ring
+        bg = scenes.make_cloud(rng, 150000, K, scenes.SAMPLE_L2C, size)
+        _check_frame(rmr, gpu, cpu, bg, [])
+    rects = []
+    for i in range(20):
+        w, h = rng.uniform(90, 140), rng.uniform(90, 140)
+        rects.append((40 + (i % 5) * 240 + rng.uniform(0, 60), 300 + (i // 5) * 170 + rng.uniform(0, 20), w, h))
+    robots = [(r, float(rng.uniform(1500, 3000)), 900) for r in rects]
+    cloud = scenes.make_cloud(rng, 150000 + 20 * 900, K, scenes.SAMPLE_L2C, size, robots)
+    nfg, ncl, nloc = _check_frame(rmr, gpu, cpu, cloud, rects)
+    assert nfg > 4096, nfg          # the grid path was taken
+    assert ncl >= 10 and nloc >= 10
