@@ -22,9 +22,10 @@ bash tools/conv_pmc.sh 256,40,40,192,192 800 conv_t32 > $OUT/r02_conv_t32_pmc.tx
   python tools/conv_bench.py 256,80,80,96,96 234,803,806,902,905 2>/dev/null
   python tools/conv_bench.py 256,20,20,288,288 214,806,905 2>/dev/null
   echo "# rocm-smi during a sustained run of kernel 800:"
-  (python tools/conv_bench.py 256,40,40,192,192 800 20000 > /dev/null 2>&1 &)
+  python tools/conv_bench.py 256,40,40,192,192 800 20000 > /dev/null 2>&1 &
+  BG=$!
   for i in 1 2 3 4 5; do sleep 2; rocm-smi --showpower --showmaxpower --showclocks 2>/dev/null | grep -E "Package Power|sclk" | tr "\n" " "; echo; done
-  wait
+  wait $BG
 } > $OUT/r02_conv_clock.txt 2>&1
 RMR_FP8=1 python tools/layer_profile.py 256 12 > $OUT/r02_layer_profile_b256_fp8_${TAG}.txt 2>&1
 python bench.py --config 4 --steps 5 --warmup 1 > $OUT/r02_bench_config4_fp8_${TAG}.json 2> $OUT/bench_fp8.log
