@@ -315,6 +315,38 @@ def main():
             sync_all()
             stats = prof.read()
 
+    # ---- 4b. per-stage breakdown: one more step with events around EVERY launch.  Stages run on
+    # different streams and overlap (locate under detect), so the figures add up to more than a step.
+    stage_ms = None
+    if not args.no_profile and rank == 0:
+        with rmr.profile(local) as prof:
+            step()
+            sync_all()
+            all_stats = prof.read()
+        stage_ms = {"first layer + letterbox sampling (car + armor)": 0.0, "network, car stage": 0.0, "network, armor stage": 0.0,
+                    "head decode": 0.0, "box decode + NMS + restore": 0.0, "locate: update (scatter + diff)": 0.0,
+                    "locate: cluster": 0.0, "locate: search": 0.0, "other": 0.0}
+        for k, v in all_stats.items():
+            ms = v["total_ms"]
+            if "stem" in k or k == "letterbox":
+                stage_ms["first layer + letterbox sampling (car + armor)"] += ms
+            elif k.startswith("conv "):
+                n_img = int(k.split()[1][1:])   # "conv n<images> M<rows> ...": the car launches carry B images
+                stage_ms["network, car stage" if n_img == B and K != 1 else "network, armor stage" if K > 0 else "network, car stage"] += ms
+            elif k in ("head_decode", "sppf_pools", "upsample2x", "quant_f8"):
+                stage_ms["head decode" if k == "head_decode" else "network, armor stage"] += ms
+            elif k == "postprocess":
+                stage_ms["box decode + NMS + restore"] += ms
+            elif k in ("loc_scatter", "loc_diff"):
+                stage_ms["locate: update (scatter + diff)"] += ms
+            elif k == "loc_cluster":
+                stage_ms["locate: cluster"] += ms
+            elif k == "loc_search":
+                stage_ms["locate: search"] += ms
+            else:
+                stage_ms["other"] += ms
+        stage_ms = {k: round(v, 3) for k, v in stage_ms.items()}
+
     # ---- 5. the step's inputs over PCIe, on their own -----------------------------------------------------
     h2d_ms = None
     if rank == 0:
@@ -398,6 +430,7 @@ def main():
                          "algorithmic_gflop_per_launch": round(conv["flops"] / max(conv["launches"], 1) / 1e9, 4),
                          "measured_in": f"{psteps} profiled step(s) after the headline loop (events on the detector's streams)"},
             "layer_roofline": layer_roofline,
+            "stage_ms_per_step": stage_ms,
             "steady_state": steady,
             "h2d_ms_per_step": None if h2d_ms is None else round(h2d_ms, 3),
             "value_incl_h2d": None if h2d_ms is None else round(B * world / (dt / args.steps + h2d_ms * 1e-3), 2),

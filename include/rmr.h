@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RMR_ABI_VERSION 2
+#define RMR_ABI_VERSION 3
 
 typedef int rmr_status;
 enum {
@@ -373,7 +373,7 @@ rmr_status rmr_pipeline_run_streams(rmr_robot_detector* rd, rmr_locator* const* 
 
 /* HIP-event timing of the library's own launches, on the streams they run on */
 typedef struct {
-    char name[48];
+    char name[64];
     long long launches;
     double total_ms;
     double flops;  /* algorithmic FLOPs summed over the launches */

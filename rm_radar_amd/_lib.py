@@ -107,7 +107,7 @@ class TrackInfo(C.Structure):
 
 
 class KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_longlong), ("total_ms", C.c_double),
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_longlong), ("total_ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 

@@ -279,7 +279,7 @@ static void launch_stem(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, const Le
     const char* pname = "conv_igemm_f16";
     if (per_layer && ctx.prof.on) {
         char buf[56];
-        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d stem%s", a.M, a.Cout_pad, a.K, a.KH, a.stride,
+        snprintf(buf, sizeof(buf), "conv n%d M%d N%d K%d k%d s%d stem%s", a.N, a.M, a.Cout_pad, a.K, a.KH, a.stride,
                  descs ? "+letterbox" : "");
         std::lock_guard<std::mutex> lk(name_mu);
         pname = names.emplace(buf, buf).first->second.c_str();

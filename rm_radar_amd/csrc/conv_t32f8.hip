@@ -612,8 +612,8 @@ void launch_conv_t32f8(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile)
     static std::map<std::string, std::string> names;
     const char* pname = "conv_igemm_f8";
     if (per_layer && ctx.prof.on) {
-        char buf[48];
-        snprintf(buf, sizeof(buf), "conv M%d N%d K%d k%d s%d f%d", a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
+        char buf[64];
+        snprintf(buf, sizeof(buf), "conv n%d M%d N%d K%d k%d s%d f%d", a.N, a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
         std::lock_guard<std::mutex> lk(name_mu);
         pname = names.emplace(buf, buf).first->second.c_str();
     }
