@@ -173,9 +173,9 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         a.in_bytes = (unsigned)(hx.size() * sizeof(__half));
         a.wt_bytes = (unsigned)(packed.size() * sizeof(__half));
         DevBuf<__half> dw32;
-        if (kh == 3 && kw == 3 && cin_pad % 32 == 0) {
+        if (kh == kw && (kh == 3 || kh == 1) && cin_pad % 32 == 0) {
             std::vector<__half> p32;
-            pack_conv_weights_t32(packed.data(), cout_pad, cin_pad, a.Kp, p32);
+            pack_conv_weights_t32(packed.data(), cout_pad, cin_pad, a.Kp, p32, kh * kw);
             dw32.alloc(p32.size());
             RMR_HIP(hipMemcpyAsync(dw32.p, p32.data(), p32.size() * sizeof(__half), hipMemcpyHostToDevice, ctx.stream));
             RMR_HIP(hipStreamSynchronize(ctx.stream));  // p32 dies at the end of this block
@@ -185,7 +185,7 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         // conv_t32f8 (ids 900..): e4m3 weights with one scale per output channel, the input quantised on the device
         DevBuf<unsigned char> dw8, dx8;
         DevBuf<float> dws;
-        if (tile >= 900 && tile < 1000 && kh == 3 && kw == 3) {
+        if (tile >= 900 && tile < 950 && kh == 3 && kw == 3) {
             std::vector<unsigned char> p8;
             std::vector<float> ws;
             pack_conv_weights_t32f8(packed.data(), cout_pad, cin_pad, a.Kp, p8, ws);
@@ -211,10 +211,15 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             RMR_HIP(hipMemsetAsync(dtiming.p, 0, 64, ctx.stream));
             a.timing = dtiming.p;
         }
-        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..799: conv_pw variant; 800..899: conv_t32 tile
+        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..799: conv_pw variant; 800..899: conv_t32 tile; 900..949: conv_t32f8 tile; 950..999: conv_g32 tile
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
-        } else if (tile >= 900 && tile < 1000) {
+        } else if (tile >= 950 && tile < 1000) {
+            const int t = tile - 950;
+            if (t >= conv_g32_num_tiles() || !conv_g32_supported(a, t))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: g32 tile %d cannot run this layer", t);
+            launch_conv_g32(ctx, ctx.stream, a, t);
+        } else if (tile >= 900 && tile < 950) {
             const int t = tile - 900;
             if (t >= conv_t32f8_num_tiles() || !conv_t32f8_supported(a, t))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: fp8 tile %d cannot run this layer", t);
@@ -318,7 +323,7 @@ rmr_status rmr_quant_e4m3(int device, const float* x, int n, unsigned char* out)
 
 // One layer on device-resident f16 data, timed with HIP events: the kernel-development loop (tools/conv_bench.py).
 // x: random f16 NHWC (one image's worth replicated), f16 output, optional residual; `tile` as in rmr_conv2d
-// (only the tiled families: 0..299, 800..899).  ms_out = mean launch time over `reps` launches.
+// (only the tiled families: 0..299, 800..999).  ms_out = mean launch time over `reps` launches.
 rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, int k, int stride, int residual, int tile,
                           int reps, float* ms_out) {
     return guarded([&] {
@@ -369,9 +374,9 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
             a.res = dr.p;
             a.res_cs = cout;
         }
-        if (k == 3 && cin % 32 == 0) {
+        if ((k == 3 || k == 1) && cin % 32 == 0) {
             std::vector<__half> p32;
-            pack_conv_weights_t32(hw.data(), cout, cin, a.Kp, p32);
+            pack_conv_weights_t32(hw.data(), cout, cin, a.Kp, p32, k * k);
             dw32.alloc(p32.size());
             RMR_HIP(hipMemcpy(dw32.p, p32.data(), p32.size() * 2, hipMemcpyHostToDevice));
             a.wt_t32 = dw32.p;
@@ -379,7 +384,7 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         }
         DevBuf<unsigned char> dw8, dx8;
         DevBuf<float> dws;
-        if (k == 3 && tile >= 900 && tile < 1000) {
+        if (k == 3 && tile >= 900 && tile < 950) {
             std::vector<unsigned char> p8;
             std::vector<float> ws;
             pack_conv_weights_t32f8(hw.data(), cout, cin, a.Kp, p8, ws);
@@ -418,7 +423,11 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         a.in_bytes = (unsigned)(n * img_in * 2);
         a.wt_bytes = (unsigned)(hw.size() * 2);
         const auto launch = [&] {
-            if (tile >= 900 && tile < 1000) {
+            if (tile >= 950 && tile < 1000) {
+                if (tile - 950 >= conv_g32_num_tiles() || !conv_g32_supported(a, tile - 950))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: g32 tile %d cannot run this layer", tile - 950);
+                launch_conv_g32(ctx, ctx.stream, a, tile - 950);
+            } else if (tile >= 900 && tile < 950) {
                 if (tile - 900 >= conv_t32f8_num_tiles() || !conv_t32f8_supported(a, tile - 900))
                     fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: fp8 tile %d cannot run this layer", tile - 900);
                 launch_conv_t32f8(ctx, ctx.stream, a, tile - 900);

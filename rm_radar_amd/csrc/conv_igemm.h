@@ -124,7 +124,14 @@ int conv_t32_num_tiles();
 ConvTile conv_t32_tile(int id);
 bool conv_t32_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
-void pack_conv_weights_t32(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out);
+// taps = KH * KW of the layer (9, or 1 for the 1x1 layers conv_g32 runs)
+void pack_conv_weights_t32(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out, int taps = 9);
+// 1x1 and 3x3 layers of any stride with Cin % 32 == 0 on the same skeleton (conv_g32.hip): the pixel rows of
+// every (tap, chunk) stage are gathered by the DMA next to the stage's weight slice (a.wt_t32)
+int conv_g32_num_tiles();
+ConvTile conv_g32_tile(int id);
+bool conv_g32_supported(const ConvArgs& a, int tile);  // tile < 0: any
+void launch_conv_g32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
 // the fp8 form (conv_t32f8.hip): e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4, f16 output
 int conv_t32f8_num_tiles();
 ConvTile conv_t32f8_tile(int id);

@@ -1,0 +1,177 @@
+// conv_t32_common.h -- what the 32x32x16 convolution kernels (conv_t32.hip, conv_g32.hip) share: the LDS-DMA
+// and wait wrappers, the constant-index loop, and the epilogue (bias, SiLU, shortcut, f16 / f32 stores).
+#pragma once
+#include <type_traits>
+
+#include "conv_igemm.h"
+
+namespace rmr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace t32 {
+
+__device__ __forceinline__ float silu_t(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// LDS-DMA: 64 lanes x 16 bytes land at lds_addr + lane * 16; source = rsrc base + voff + soff
+__device__ __forceinline__ void dma16s(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+template <int T>
+using tap_c = std::integral_constant<int, T>;
+
+// f(integral_constant<0>) ... f(integral_constant<N-1>): a loop whose index is a constant expression
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (K < N) {
+        f(std::integral_constant<int, K>{});
+        static_for<K + 1, N>(f);
+    }
+}
+
+// Epilogue of one tile: bias, SiLU, residual; a lane holds 4 x 4 consecutive channels of one pixel per fragment
+// (pixel = lane & 31 of fragment row i, channels 8 g + 4 (lane >> 5) + 0..3 of fragment column j).
+// EPI: 0 = results leave through v_permlane32_swap pairs as 16-byte stores (32 contiguous bytes per pixel),
+//      1 = through a per-wave LDS stage at smem + stg_base as whole rows (NREP * 64 contiguous bytes per pixel).
+template <int MREP, int NREP, int EPI>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int m0, int n0,
+                                         int wm, int wn, int lane) {
+    constexpr int STG_PITCH = NREP * 64 + 16;   // bytes per pixel row of the epilogue stage
+    const int fr = lane & 31, kq = lane >> 5;
+    const int cq = kq * 4;
+    const bool wide = !a.out32 && ((a.out_cs | a.out_co) & 7) == 0;   // 16-byte stores need 8-channel alignment
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + (wm * MREP + i) * 32 + fr;
+        if (!wide) {
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n = n0 + (wn * NREP + j) * 32 + gq * 8 + cq;
+                    const float4 b = *(const float4*)(a.bias + n);
+                    float v[4] = {acc[i][j][gq * 4 + 0] + b.x, acc[i][j][gq * 4 + 1] + b.y, acc[i][j][gq * 4 + 2] + b.z,
+                                  acc[i][j][gq * 4 + 3] + b.w};
+                    if (a.act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = silu_t(v[r]);
+                    }
+                    if (a.res) {
+                        union {
+                            uint2 u;
+                            _Float16 h[4];
+                        } rr;
+                        rr.u = *(const uint2*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rr.h[r];
+                    }
+                    if (a.out32) {
+                        *(float4*)(a.out32 + (long)m * a.out_cs + a.out_co + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        union {
+                            uint2 u;
+                            _Float16 h[4];
+                        } o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o.h[r] = (_Float16)v[r];
+                        *(uint2*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + n) = o.u;
+                    }
+                }
+            continue;
+        }
+        // f16 output in 16-byte pieces.  Channel groups gq and gq + 1 of a lane pair (l, l + 32) hold
+        // channels 8 gq + {0..3 | 4..7} and 8 gq + 8 + {0..3 | 4..7}: one v_permlane32_swap per dword
+        // gives the lower lane all eight channels of group gq and the upper lane those of group gq + 1.
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const int nb = n0 + (wn * NREP + j) * 32 + gp * 16;     // first channel of the pair of groups
+                float v[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 b = *(const float4*)(a.bias + nb + h * 8 + cq);
+                    const int r0 = (gp * 2 + h) * 4;
+                    v[h * 4 + 0] = acc[i][j][r0 + 0] + b.x;
+                    v[h * 4 + 1] = acc[i][j][r0 + 1] + b.y;
+                    v[h * 4 + 2] = acc[i][j][r0 + 2] + b.z;
+                    v[h * 4 + 3] = acc[i][j][r0 + 3] + b.w;
+                }
+                if (a.act) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = silu_t(v[r]);
+                }
+                const int nl = nb + kq * 8;   // the eight channels this lane ends up with
+                union {
+                    uint4 u;
+                    _Float16 h[8];
+                    unsigned w[4];
+                } o;
+                if (a.res) {
+                    // the shortcut is added in f32 before the one rounding, so the values are exchanged as f32
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[r]), __float_as_uint(v[4 + r]), false, false);
+                        v[r] = __uint_as_float(sw[0]);
+                        v[4 + r] = __uint_as_float(sw[1]);
+                    }
+                    // lower lane: v[0..3] own group gq, v[4..7] the upper lane's group gq; upper lane: v[0..3] the lower
+                    // lane's group gq + 1, v[4..7] own -- in both cases channels nl .. nl + 7 in order
+                    union {
+                        uint4 u;
+                        _Float16 h[8];
+                    } rr;
+                    if (m < a.M) rr.u = *(const uint4*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + nl);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o.h[r] = (_Float16)(v[r] + (float)rr.h[r]);
+                } else {
+                    union {
+                        uint2 u;
+                        _Float16 h[4];
+                        unsigned w[2];
+                    } lo2, hi2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lo2.h[r] = (_Float16)v[r], hi2.h[r] = (_Float16)v[4 + r];
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(lo2.w[0], hi2.w[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(lo2.w[1], hi2.w[1], false, false);
+                    o.w[0] = s0[0];
+                    o.w[1] = s1[0];
+                    o.w[2] = s0[1];
+                    o.w[3] = s1[1];
+                }
+                if constexpr (EPI == 0) {
+                    if (m < a.M) *(uint4*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + nl) = o.u;
+                } else {
+                    *(uint4*)(smem + stg_base + fr * STG_PITCH + (j * 32 + gp * 16 + kq * 8) * 2) = o.u;
+                }
+            }
+        if constexpr (EPI == 1) {
+            // the wave's 32 x (NREP * 32) block leaves as whole rows: NREP * 4 lanes per pixel
+            constexpr int CPP = NREP * 4;   // 16-byte chunks per pixel
+            const int mb = m0 + (wm * MREP + i) * 32;
+            const int nw0 = n0 + wn * NREP * 32;
+#pragma unroll
+            for (int it = 0; it < (32 * CPP) / 64; ++it) {
+                const int f = it * 64 + lane;
+                const int px = f / CPP, ch = f % CPP;
+                const uint4 vv = *(const uint4*)(smem + stg_base + px * STG_PITCH + ch * 16);
+                if (mb + px < a.M) *(uint4*)((_Float16*)a.out + (long)(mb + px) * a.out_cs + a.out_co + nw0 + ch * 8) = vv;
+            }
+        }
+    }
+}
+
+}  // namespace t32
+}  // namespace rmr

@@ -146,7 +146,7 @@ int Yolov8::add_conv_weights(const WeightPack& p, const std::string& name, int c
     return (int)convs_.size() - 1;
 }
 
-// the second copy of a 3x3 layer's weights, as the LDS images conv_t32 streams
+// the second copy of a 3x3 or 1x1 layer's weights, as the LDS images conv_t32 / conv_g32 stream
 void Yolov8::upload_t32(ConvW& cw, const std::vector<__half>& packed) {
     if (fp8_ && fp8_layer_ && cw.k == 3 && cw.cin % 16 == 0 && cw.cin >= 64) {
         std::vector<unsigned char> p8;
@@ -157,9 +157,9 @@ void Yolov8::upload_t32(ConvW& cw, const std::vector<__half>& packed) {
         RMR_HIP(hipMemcpy(cw.w8.p, p8.data(), p8.size(), hipMemcpyHostToDevice));
         RMR_HIP(hipMemcpy(cw.wscale.p, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (cw.k != 3 || cw.cin % 32) return;
+    if ((cw.k != 3 && cw.k != 1) || cw.cin % 32) return;
     std::vector<__half> p32;
-    pack_conv_weights_t32(packed.data(), cw.cout_pad, cw.cin, cw.Kp, p32);
+    pack_conv_weights_t32(packed.data(), cw.cout_pad, cw.cin, cw.Kp, p32, cw.k * cw.k);
     cw.w32.alloc(p32.size());
     RMR_HIP(hipMemcpy(cw.w32.p, p32.data(), p32.size() * sizeof(__half), hipMemcpyHostToDevice));
 }
@@ -639,7 +639,9 @@ void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     const int split = choice / 1000, c = choice % 1000;
     if ((a.in_slab_c || a.out_slab_c) && (c < 700 || c >= 800 || split))
         fail(RMR_ERR_LOGIC, "kernel %d cannot address planar channel groups", choice);
-    if (c >= 900) {
+    if (c >= 950) {
+        launch_conv_g32(ctx_, s, a, c - 950);
+    } else if (c >= 900) {
         launch_conv_t32f8(ctx_, s, a, c - 900);
     } else if (c >= 800) {
         launch_conv_t32(ctx_, s, a, c - 800);
@@ -690,6 +692,10 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (conv_t32_supported(a, -1))
         for (int t = 0; t < conv_t32_num_tiles(); ++t)
             if (conv_t32_supported(a, t)) cands.push_back(800 + t);
+    // 1x1 and strided 3x3 layers on the same skeleton (a chip-filling number of 256-pixel tiles only)
+    if (conv_g32_supported(a, -1) && !conv_t32_supported(a, -1) && a.M >= 128 * ctx_.num_cus)
+        for (int t = 0; t < conv_g32_num_tiles(); ++t)
+            if (conv_g32_supported(a, t)) cands.push_back(950 + t);
     // fragment-direct tiles only where the staged kernels cannot fill the chip
     if (!slabbed && conv_direct_supported(a, -1) && a.M <= 64 * ctx_.num_cus)
         for (int t = 0; t < conv_direct_num_tiles(); ++t)
@@ -818,6 +824,7 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
                conv_dma_splitk_ws_floats(a, c - 100, split) <= kSplitKWsFloats;
     }
     if (a.in8) return !split && c >= 900 && c - 900 < conv_t32f8_num_tiles() && conv_t32f8_supported(a, c - 900);
+    if (c >= 950) return c - 950 < conv_g32_num_tiles() && conv_g32_supported(a, c - 950);
     if (c >= 900) return false;
     if (c >= 800) return c - 800 < conv_t32_num_tiles() && conv_t32_supported(a, c - 800);
     if (c >= 700) return c - 700 < conv_pw_num_variants() && conv_pw_supported(a, c - 700);

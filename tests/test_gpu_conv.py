@@ -290,6 +290,34 @@ def test_conv_t32_every_tile(rmr):
                    False, tile=806)  # Cin = 48 is not a multiple of 32
 
 
+def test_conv_g32_every_tile(rmr):
+    # the gathered form of conv_t32 (conv_g32.hip, ids 950..): 1x1 layers and 3x3 layers of any stride, one
+    # (tap, 32-channel chunk) stage = the tile's pixel rows at that tap + the weight slice, padding as
+    # out-of-range DMA offsets
+    tiles = [(256, 192, 1), (512, 96, 1), (256, 192, 3), (512, 96, 3), (256, 128, 1), (256, 128, 3)]
+    for t, (bm, bn, k) in enumerate(tiles):
+        cmin = 32 * (6 if k == 1 else 1)   # a tile has at least a ring of stages
+        run_case(rmr, 3, 20, 20, cmin, bn, k, 1, True, True, tile=950 + t, seed=t)             # ~5 tiles
+        run_case(rmr, 1, 19, 23, cmin + 32, bn * 2, k, 1, True, False, tile=950 + t, seed=20 + t)  # odd W, ragged M, 2 channel tiles
+        if k == 3:
+            run_case(rmr, 2, 20, 20, 64, bn, 3, 2, True, False, tile=950 + t, seed=40 + t)     # stride 2, even size
+            run_case(rmr, 1, 19, 23, 32, bn, 3, 2, True, False, tile=950 + t, seed=50 + t)     # stride 2, odd size
+    run_case(rmr, 2, 40, 40, 768, 384, 1, 1, True, False, tile=950, seed=70)    # C2f cv2 shape: 24 stages
+    run_case(rmr, 1, 20, 20, 1152, 576, 1, 1, True, False, tile=950, seed=71)   # SPPF cv2 shape: 3 channel tiles
+    run_case(rmr, 1, 80, 80, 192, 384, 3, 2, True, False, tile=952, seed=72)    # model.5 shape: 54 stages
+    run_case(rmr, 1, 5, 5, 192, 96, 1, 1, False, False, tile=951, seed=73)      # tile far larger than the image
+    # more tiles than workgroups: the stream crosses tile boundaries, the channel tile changes under it
+    run_case(rmr, 300, 20, 20, 192, 192, 1, 1, True, True, tile=950, seed=74)   # 469 tiles on 256 workgroups
+    run_case(rmr, 150, 40, 40, 32, 192, 3, 2, True, False, tile=952, seed=75)   # 235 x ... strided, one chunk per tile
+    run_case(rmr, 330, 20, 20, 128, 192, 1, 1, True, False, tile=951, seed=76)  # 258 x 2 tiles of 512 x 96
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 4, 4, 64), np.float32), np.zeros((192, 64, 1, 1), np.float32), None, 1, 0,
+                   False, tile=950)  # two stages: shorter than the ring
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 4, 4, 192), np.float32), np.zeros((192, 192, 3, 3), np.float32), None, 1, 1,
+                   False, tile=950)  # a 1x1 tile on a 3x3 layer
+
+
 def _e4m3(a):
     """OCP e4m3fn rounding (nearest even, saturating), as the packer and the device quantiser do it"""
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).clamp(-448, 448).to(torch.float8_e4m3fn).float().numpy()
