@@ -25,11 +25,11 @@ K_OPT_BATCH_SIZE = 4
 
 class SampleRadar:
     def __init__(self, car_engine_path, armor_engine_path, image_size, intrinsic, lidar_to_camera,
-                 world_to_camera, lidar_noise=None, device=0, **locator_kwargs):
+                 world_to_camera, lidar_noise=None, device=0, detector_kwargs=None, **locator_kwargs):
         # sample_radar.h:73-92: RobotDetector(car, armor, image_size, kClassNum, kMaxBatchSize,
         # kOptBatchSize) and Locator(image_size.width, image_size.height, K, L2C, W2C)
         self.detector = RobotDetector(car_engine_path, armor_engine_path, image_size, K_CLASS_NUM,
-                                      K_MAX_BATCH_SIZE, K_OPT_BATCH_SIZE, device=device)
+                                      K_MAX_BATCH_SIZE, K_OPT_BATCH_SIZE, device=device, **(detector_kwargs or {}))
         self.locator = Locator(image_size[0], image_size[1], intrinsic, lidar_to_camera,
                                world_to_camera, device=device, **locator_kwargs)
         # sample_radar.h:68: Tracker(lidar_noise, kClassNum); None = stop after search()

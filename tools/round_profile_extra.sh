@@ -9,6 +9,8 @@ mkdir -p $OUT
 hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_power.hip -o /tmp/mfma_power && /tmp/mfma_power > $OUT/r02_mfma_power_f16.txt
 hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_fp8_power.hip -o /tmp/mfma_fp8 && /tmp/mfma_fp8 > $OUT/r02_mfma_power_fp8.txt
 bash tools/conv_pmc.sh 256,40,40,192,192 800 conv_t32 > $OUT/r02_conv_t32_pmc.txt 2>&1
+bash tools/conv_pmc.sh 256,80,80,192,384,3,2 952 conv_g32 > $OUT/r02_conv_g32_pmc.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/lds_dma_rate.hip -o /tmp/lds_dma && /tmp/lds_dma > $OUT/r02_lds_dma_rate.txt
 {
   echo "# effective clock (GRBM_GUI_ACTIVE summed over 8 XCDs / duration: divide the printed GHz by 8) and MFMA-busy fraction"
   echo "# (printed fraction x 8) of one layer, M409600 N192 K1728, random operands unless noted"
@@ -21,6 +23,12 @@ bash tools/conv_pmc.sh 256,40,40,192,192 800 conv_t32 > $OUT/r02_conv_t32_pmc.tx
   python tools/conv_bench.py 256,40,40,192,192 233,800,806,900,906 2>/dev/null
   python tools/conv_bench.py 256,80,80,96,96 234,803,806,902,905 2>/dev/null
   python tools/conv_bench.py 256,20,20,288,288 214,806,905 2>/dev/null
+  echo "# strided 3x3 and 1x1 layers: conv_dma (1xx) against conv_g32 (95x)"
+  python tools/conv_bench.py 256,160,160,96,192,3,2 144,952 2>/dev/null
+  python tools/conv_bench.py 256,80,80,192,384,3,2 144,952 2>/dev/null
+  python tools/conv_bench.py 256,40,40,384,576,3,2 144,952 2>/dev/null
+  python tools/conv_bench.py 256,40,40,768,384,1,1 131,950 2>/dev/null
+  python tools/conv_bench.py 256,20,20,1152,576,1,1 144,950 2>/dev/null
   echo "# rocm-smi during a sustained run of kernel 800:"
   python tools/conv_bench.py 256,40,40,192,192 800 20000 > /dev/null 2>&1 &
   BG=$!
