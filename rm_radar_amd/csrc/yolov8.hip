@@ -692,8 +692,9 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (conv_t32_supported(a, -1))
         for (int t = 0; t < conv_t32_num_tiles(); ++t)
             if (conv_t32_supported(a, t)) cands.push_back(800 + t);
-    // 1x1 and strided 3x3 layers on the same skeleton (a chip-filling number of 256-pixel tiles only)
-    if (conv_g32_supported(a, -1) && !conv_t32_supported(a, -1) && a.M >= 128 * ctx_.num_cus)
+    // 1x1 and strided 3x3 layers on the same skeleton (a chip-filling number of 256-pixel tiles only, unless a test
+    // pins the family)
+    if (conv_g32_supported(a, -1) && !conv_t32_supported(a, -1) && (a.M >= 128 * ctx_.num_cus || std::getenv("RMR_TUNE_ONLY")))
         for (int t = 0; t < conv_g32_num_tiles(); ++t)
             if (conv_g32_supported(a, t)) cands.push_back(950 + t);
     // fragment-direct tiles only where the staged kernels cannot fill the chip
@@ -839,6 +840,8 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
 }
 
 // header: "rmr-tune <version> <ops> <w> <h> <plan signature> <CUs> <device name without blanks>"
+// (the version moves whenever the set of candidate kernels does: 11 = conv_g32 added)
+static constexpr int kTuneFileVersion = 11;
 static std::string device_tag(int device) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return "unknown";
@@ -857,7 +860,7 @@ void Yolov8::load_tuning() {
     int version = 0, n_ops = 0, w = 0, h = 0, cus = 0;
     unsigned long long sig = 0;
     f >> tag >> version >> n_ops >> w >> h >> sig >> cus >> dev;
-    if (tag != "rmr-tune" || version != 10 || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_ || sig != plan_signature())
+    if (tag != "rmr-tune" || version != kTuneFileVersion || n_ops != (int)ops_.size() || w != in_w_ || h != in_h_ || sig != plan_signature())
         return;
     // timings from another chip say nothing about this one (a pinned plan is taken as it is)
     if (!pinned_ && (cus != ctx_.num_cus || dev != device_tag(ctx_.device))) return;
@@ -875,7 +878,7 @@ void Yolov8::save_tuning() {
     {
         std::ofstream f(tmp, std::ios::trunc);
         if (!f) return;  // read-only location: tune again next time
-        f << "rmr-tune 10 " << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << ' ' << plan_signature() << ' ' << ctx_.num_cus << ' '
+        f << "rmr-tune " << kTuneFileVersion << ' ' << ops_.size() << ' ' << in_w_ << ' ' << in_h_ << ' ' << plan_signature() << ' ' << ctx_.num_cus << ' '
           << device_tag(ctx_.device) << "\n";
         for (const auto& kv : tuned_) f << kv.first.first << ' ' << kv.first.second << ' ' << kv.second << "\n";
         if (!f) {

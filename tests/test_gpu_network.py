@@ -313,6 +313,27 @@ def test_network_on_the_pointwise_kernels(rmr, packs, refs, images, oracle, monk
     assert sum(1 for t in tuned if 700 <= int(t[2]) < 800) >= 10
 
 
+def test_network_on_the_gathered_kernels(rmr, packs, refs, images, oracle, monkeypatch, tmp_path):
+    """conv_g32.hip under the whole network: RMR_TUNE_ONLY=950-999 makes every layer it supports (the five 3x3 /
+    stride-2 layers with Cin % 32 == 0, the 1x1 layers of K >= 128 that carry neither slabs nor a folded upsample)
+    run on it, at a batch size where the autotuner would not offer it; same oracle, same tolerance."""
+    import shutil
+    pack = str(tmp_path / "armor_g32.rmrw")  # its own tuning cache
+    shutil.copy(packs[1], pack)
+    monkeypatch.setenv("RMR_TUNE_ONLY", "950-999")
+    n = 5
+    det = rmr.Detector(pack, 12, (2592, 2048), n, conf_thresh=0.5)
+    batch = [images[i % 3] for i in range(n)]
+    got, _ = det.infer(batch)
+    det.close()
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    want = refs["armor"][1].forward(blobs)
+    for i in range(n):
+        _check_head(got[i:i + 1], want[i % 3:i % 3 + 1], 2.0, 1e-2)
+    tuned = [l.split() for l in open(pack + ".tune").read().splitlines()[1:]]
+    assert sum(1 for t in tuned if 950 <= int(t[2]) < 1000) >= 10
+
+
 def test_interleaved_chunks_plan_still_matches(rmr, packs, refs, images, oracle, monkeypatch):
     """RMR_SLABS=0: every C2f keeps its chunks as channel slices of one wide buffer (the layout before
     conv_pw could address planar channel groups); the fallback for shapes conv_pw does not cover."""
