@@ -48,7 +48,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_g32_kernel(const ConvArgs a,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
     const unsigned lds0 = sgpr((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
-    constexpr int scratch_off = R * SLICE;   // where the DMA slots with nothing to fetch land
+    constexpr int scratch_off = R * SLICE;   // where the DMA slots with nothing to fetch land (only if (NA + NB) % NW)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -296,24 +296,32 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_g32_kernel(const ConvArgs a,
 }
 
 struct G32Tile {
-    int bm, bn, threads, taps, ring;
+    int bm, bn, threads, taps, ring, wgs_per_cu;
     void (*kernel)(const ConvArgs, int);
 };
 
-#define G32(WM, WN, MR, NR, T, R) \
-    { WM * MR * 32, WN * NR * 32, WM * WN * 64, T, R, conv_g32_kernel<WM, WN, MR, NR, T, R> }
+#define G32(WM, WN, MR, NR, T, R, WPC) \
+    { WM * MR * 32, WN * NR * 32, WM * WN * 64, T, R, WPC, conv_g32_kernel<WM, WN, MR, NR, T, R> }
 
 const G32Tile kG32Tiles[] = {
-    G32(4, 2, 2, 3, 1, 5),   // 0: 1x1, 256 x 192
-    G32(8, 1, 2, 3, 1, 4),   // 1: 1x1, 512 x 96
-    G32(4, 2, 2, 3, 9, 5),   // 2: 3x3, 256 x 192
-    G32(8, 1, 2, 3, 9, 4),   // 3: 3x3, 512 x 96
-    G32(4, 2, 2, 2, 1, 6),   // 4: 1x1, 256 x 128
-    G32(4, 2, 2, 2, 9, 6),   // 5: 3x3, 256 x 128
+    G32(4, 2, 2, 3, 1, 5, 1),   // 0: 1x1, 256 x 192
+    G32(8, 1, 2, 3, 1, 4, 1),   // 1: 1x1, 512 x 96
+    G32(4, 2, 2, 3, 9, 5, 1),   // 2: 3x3, 256 x 192
+    G32(8, 1, 2, 3, 9, 4, 1),   // 3: 3x3, 512 x 96
+    G32(4, 2, 2, 2, 1, 6, 1),   // 4: 1x1, 256 x 128
+    G32(4, 2, 2, 2, 9, 6, 1),   // 5: 3x3, 256 x 128
+    // two four-wave workgroups per CU (80 KiB each: a ring of four 20 KiB stages, every DMA slot live): one's
+    // epilogue under the other's K loop
+    G32(2, 2, 2, 3, 1, 4, 2),   // 6: 1x1, 128 x 192
+    G32(2, 2, 2, 3, 9, 4, 2),   // 7: 3x3, 128 x 192
 };
 constexpr int kNumG32Tiles = sizeof(kG32Tiles) / sizeof(kG32Tiles[0]);
 
-int g32_lds_bytes(const G32Tile& t) { return t.ring * (t.bm + t.bn) * 64 + 1024; }
+// the scratch KiB behind the ring exists only where a wave has a DMA slot without a block
+int g32_lds_bytes(const G32Tile& t) {
+    const bool dead_slots = ((t.bm + t.bn) / 16) % (t.threads / 64) != 0;
+    return t.ring * (t.bm + t.bn) * 64 + (dead_slots ? 1024 : 0);
+}
 
 }  // namespace
 
@@ -343,8 +351,8 @@ void launch_conv_g32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     });
     const int lds = g32_lds_bytes(t);
     const int n_tiles = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
-    // persistent: one workgroup per CU (a multiple of 8: a workgroup stays on its XCD), each walks tiles
-    const int grid = std::min((n_tiles + 7) / 8 * 8, ctx.num_cus);
+    // persistent: wgs_per_cu workgroups per CU (a multiple of 8: a workgroup stays on its XCD), each walks tiles
+    const int grid = std::min((n_tiles + 7) / 8 * 8, ctx.num_cus * t.wgs_per_cu);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
     static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;

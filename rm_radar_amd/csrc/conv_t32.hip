@@ -382,6 +382,12 @@ const T32Tile kT32Tiles[] = {
     T32(8, 1, 1, 3, 10, 4, 0, 2),   // 6: 256 x 96
     T32(8, 1, 1, 2, 12, 4, 0, 2),   // 7: 256 x 64
     T32(4, 2, 1, 3, 4, 4, 0, 2),    // 8: 128 x 192
+    // two FOUR-wave workgroups per CU (one wave per SIMD each, full 64 x 96 wave tiles, up to 256 VGPRs): the two
+    // drift apart on their own, so one's epilogue runs under the other's K loop, and a barrier joins four waves
+    T32(2, 2, 2, 3, 2, 4, 0, 2),    // 9: 128 x 192
+    T32(4, 1, 2, 3, 4, 4, 0, 2),    // 10: 256 x 96
+    T32(2, 2, 2, 2, 2, 4, 0, 2),    // 11: 128 x 128
+    T32(4, 1, 2, 2, 4, 4, 0, 2),    // 12: 256 x 64
 };
 constexpr int kNumT32Tiles = sizeof(kT32Tiles) / sizeof(kT32Tiles[0]);
 

@@ -270,7 +270,8 @@ def test_conv_t32_every_tile(rmr):
     # 32x32x16-MFMA 3x3 / stride-1 kernel (conv_t32.hip): ids 800..; persistent workgroups walking tiles with a
     # continuous DMA stream, weights pre-packed as LDS images, fragment reads ahead of the MFMAs across the
     # barrier, lane masks for the border taps, 16-byte stores (lane-pair exchange or rows staged through LDS)
-    tiles = [(256, 192), (256, 192), (256, 192), (512, 96), (256, 256), (512, 64), (256, 96), (256, 64), (128, 192)]
+    tiles = [(256, 192), (256, 192), (256, 192), (512, 96), (256, 256), (512, 64), (256, 96), (256, 64), (128, 192),
+             (128, 192), (256, 96), (128, 128), (256, 64)]   # 9..12: two four-wave workgroups per CU
     for t, (bm, bn) in enumerate(tiles):
         run_case(rmr, 3, 20, 20, 64, bn, 3, 1, True, True, tile=800 + t, seed=t)            # 3 images in ~5 tiles
         run_case(rmr, 1, 19, 23, 32, bn * 2, 3, 1, True, False, tile=800 + t, seed=40 + t)  # odd W, ragged M, 1 chunk
@@ -285,6 +286,8 @@ def test_conv_t32_every_tile(rmr):
     run_case(rmr, 160, 20, 20, 32, 192, 3, 1, True, True, tile=806, seed=76)  # 250 x 2 tiles of 256 x 96 on 512 slots... and
     run_case(rmr, 300, 20, 20, 32, 192, 3, 1, True, True, tile=802, seed=77)  # 469 tiles of 256 x 192 on 256 workgroups
     run_case(rmr, 330, 20, 20, 32, 96, 3, 1, True, False, tile=806, seed=78)  # 516 tiles on 512 workgroups: a few walk two
+    run_case(rmr, 200, 20, 20, 64, 192, 3, 1, True, True, tile=809, seed=79)  # 625 tiles of 128 x 192 on 512 four-wave workgroups
+    run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, True, tile=810, seed=80)     # four-wave 256 x 96 on 80-wide maps
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 4, 4, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
                    False, tile=806)  # Cin = 48 is not a multiple of 32
@@ -294,7 +297,8 @@ def test_conv_g32_every_tile(rmr):
     # the gathered form of conv_t32 (conv_g32.hip, ids 950..): 1x1 layers and 3x3 layers of any stride, one
     # (tap, 32-channel chunk) stage = the tile's pixel rows at that tap + the weight slice, padding as
     # out-of-range DMA offsets
-    tiles = [(256, 192, 1), (512, 96, 1), (256, 192, 3), (512, 96, 3), (256, 128, 1), (256, 128, 3)]
+    tiles = [(256, 192, 1), (512, 96, 1), (256, 192, 3), (512, 96, 3), (256, 128, 1), (256, 128, 3),
+             (128, 192, 1), (128, 192, 3)]   # 6, 7: two four-wave workgroups per CU
     for t, (bm, bn, k) in enumerate(tiles):
         cmin = 32 * (6 if k == 1 else 1)   # a tile has at least a ring of stages
         run_case(rmr, 3, 20, 20, cmin, bn, k, 1, True, True, tile=950 + t, seed=t)             # ~5 tiles
@@ -310,6 +314,8 @@ def test_conv_g32_every_tile(rmr):
     run_case(rmr, 300, 20, 20, 192, 192, 1, 1, True, True, tile=950, seed=74)   # 469 tiles on 256 workgroups
     run_case(rmr, 150, 40, 40, 32, 192, 3, 2, True, False, tile=952, seed=75)   # 235 x ... strided, one chunk per tile
     run_case(rmr, 330, 20, 20, 128, 192, 1, 1, True, False, tile=951, seed=76)  # 258 x 2 tiles of 512 x 96
+    run_case(rmr, 200, 20, 20, 192, 192, 1, 1, True, True, tile=956, seed=77)   # 625 tiles on 512 four-wave workgroups
+    run_case(rmr, 200, 40, 40, 64, 192, 3, 2, True, False, tile=957, seed=78)   # the same, strided
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 4, 4, 64), np.float32), np.zeros((192, 64, 1, 1), np.float32), None, 1, 0,
                    False, tile=950)  # two stages: shorter than the ring
