@@ -419,7 +419,7 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         a.out_cs = cout;
         a.Cout_pad = cout;
         a.M = n * ho * wo;
-        a.act = 1;
+        a.act = std::getenv("RMR_BENCH_ACT") ? std::atoi(std::getenv("RMR_BENCH_ACT")) : 1;
         a.in_bytes = (unsigned)(n * img_in * 2);
         a.wt_bytes = (unsigned)(hw.size() * 2);
         const auto launch = [&] {

@@ -31,7 +31,7 @@ using namespace t32;
 // PERSISTENT like conv_t32: the DMA stream runs R - 1 stages ahead of the MFMAs and does not stop at a tile's
 // end, so the epilogue of a tile runs with the next tile's first stages in flight.
 template <int WM, int WN, int MREP, int NREP, int T, int R>
-__global__ __launch_bounds__(WM* WN * 64) void conv_g32_kernel(const ConvArgs a, const int n_tiles) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_g32_kernel(const ConvArgs a, const int n_tiles) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 32;
     constexpr int BN = WN * NREP * 32;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_g32_kernel(const ConvArgs a,
         }
 
         // ---- epilogue; the next tile's first stages are in flight meanwhile
-        epilogue<MREP, NREP, 0>(a, acc, smem, 0, m0, n0, wm, wn, lane);
+        epilogue<MREP, NREP, 0, false, false>(a, acc, smem, 0, 0, m0, n0, wm, wn, lane);
 
         if (!has_next) break;
         vb = vbn;

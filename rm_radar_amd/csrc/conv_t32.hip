@@ -49,8 +49,10 @@ using namespace t32;
 // slices of the next one and its last chunk fetches the next tile's first input range, so only the very
 // first tile of a workgroup pays a cold start, and the epilogue of a tile runs while the next tile's
 // operands are already in flight.
-template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
+// ABL (development builds only, -DRMR_T32_ABLATE): bit 0 = no MFMAs, 1 = no epilogue, 2 = epilogue without stores,
+// 3 = every DMA out of range (zeros arrive, no memory traffic), 4 = no fragment reads in the K loop.  Timing only.
+template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI, int ABL = 0>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : MREP == 1 ? 4 : 2)) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 32;
     constexpr int BN = WN * NREP * 32;
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int stg_base = zero_off + 1024 + wave * 32 * STG_PITCH;
+    const int bias_off = zero_off + 1024 + (EPI ? NW * 32 * STG_PITCH : 0);   // Cout_pad floats
 
     // tile vb -> (m0, n0); XCD-aware: the tiles of one XCD (vb & 7) are a contiguous range, n-tiles innermost
     const int nt_count = a.Cout_pad / BN;
@@ -95,9 +98,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     const int npix = a.M;        // stride 1: input and output pixels share the linear index
 
     const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
-                           sgpr(a.in_bytes), sgpr(0x00020000u)};
+                           sgpr((ABL & (8 | 64)) ? 0u : a.in_bytes), sgpr(0x00020000u)};
     const u32x4 wt_rsrc = {sgpr((unsigned)(size_t)a.wt_t32), sgpr((unsigned)((size_t)a.wt_t32 >> 32) & 0xffffu),
-                           sgpr(a.wt_t32_bytes), sgpr(0x00020000u)};
+                           sgpr((ABL & (8 | 32)) ? 0u : a.wt_t32_bytes), sgpr(0x00020000u)};
 
     // ---- DMA constants of this lane ----------------------------------------------------------
     const int lrow = lane >> 2;                                   // row inside a 16-row DMA block
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
     const unsigned scratch = sgpr(lds0 + zero_off);
 
     if (tid < 4) *(u32x4*)(smem + zero_off + tid * 16) = u32x4{0, 0, 0, 0};
+    for (int i = tid; i < a.Cout_pad; i += NW * 64) *(float*)(smem + bias_off + i * 4) = a.bias[i];
 
     // byte offset of this lane's piece of input block ia of a tile whose LDS row 0 is pixel lo, channel chunk cc
     const auto in_off = [&](int lo_l, int ia, int cc) {
@@ -163,7 +167,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
 #pragma unroll
     for (int i = 0; i < MREP; ++i) zsel[i] = zero_off - i * 2048;
     const int wlane = ring_base + (wn * NREP * 32 + fr) * 64 + ((kq ^ ((fr >> 2) & 3)) << 4);
-    const auto lds16 = [&](int off) { return *(const half8*)(smem + off); };
+    const auto lds16 = [&](int off) {
+        if constexpr (ABL & 16) {
+            half8 z = {};
+            asm volatile("" : "+v"(z) : "v"(off));
+            return z;
+        } else {
+            return *(const half8*)(smem + off);
+        }
+    };
+    const auto mma = [](half8 w, half8 x, floatx16 c) {
+        if constexpr (ABL & 1) {
+            asm volatile("" : "+v"(c) : "v"(w), "v"(x));
+            return c;
+        } else {
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
+        }
+    };
     // address of fragment 0's chunk for K-step 0 of tap t, in input buffer `abuf`
     const auto a_addr = [&](int abuf, int t) {
         const int row = a_row0 + (t / 3 - 1) * W + (t % 3 - 1);
@@ -288,8 +308,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
                 };
                 static_for<0, NM>([&](auto Kc) {
                     constexpr int k = decltype(Kc)::value;
-                    acc[k / NREP][k % NREP] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[k % NREP], xa[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
+                    acc[k / NREP][k % NREP] = mma(wa[k % NREP], xa[k / NREP], acc[k / NREP][k % NREP]);
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, D + 3>([&](auto Fc) {
                         if constexpr (decltype(Fc)::value * NM / (D + 3) == k) filler0(Fc);
@@ -298,8 +317,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
                 });
                 static_for<0, NM>([&](auto Kc) {
                     constexpr int k = decltype(Kc)::value;
-                    acc[k / NREP][k % NREP] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[k % NREP], xb[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
+                    acc[k / NREP][k % NREP] = mma(wb[k % NREP], xb[k / NREP], acc[k / NREP][k % NREP]);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (k == 0) {
                         // K-step 0 fragments of the next tap (tap 0 of the next chunk after tap 8): legal before the
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
                     }
                     return n;
                 }();
-                wait_vm<pending>();
+                if constexpr (!(ABL & 128)) wait_vm<pending>();
                 // advance the weight stream; behind a tile's last slice comes the first one of the next tile
                 // (selects, not a branch: a tap must stay one basic block, or the scheduling pins above do not hold
                 // the MFMAs in place and the compiler sinks them towards the end of the chunk)
@@ -352,7 +370,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_t32_kernel(const ConvArgs a,
         }
 
         // ---- epilogue; the next tile's first slices and input range are in flight meanwhile
-        epilogue<MREP, NREP, EPI>(a, acc, smem, stg_base, m0, n0, wm, wn, lane);
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : : "v"(acc[i][j]));
+#endif
+                }
+        } else {
+            epilogue<MREP, NREP, EPI, true, (NREP < 4), (ABL & 4) != 0>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+        }
 
         if (!has_next) break;
         vb = vbn;
@@ -369,6 +398,8 @@ struct T32Tile {
 
 #define T32(WM, WN, MR, NR, AS, R, EPI, WPC) \
     { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, NR, EPI, WPC, conv_t32_kernel<WM, WN, MR, NR, AS, R, EPI> }
+#define T32A(WM, WN, MR, NR, AS, R, EPI, WPC, ABL) \
+    { WM * MR * 32, WN * NR * 32, WM * WN * 64, AS, R, NR, EPI, WPC, conv_t32_kernel<WM, WN, MR, NR, AS, R, EPI, ABL> }
 
 const T32Tile kT32Tiles[] = {
     // one workgroup per CU (up to 256 VGPRs)
@@ -388,12 +419,38 @@ const T32Tile kT32Tiles[] = {
     T32(4, 1, 2, 3, 4, 4, 0, 2),    // 10: 256 x 96
     T32(2, 2, 2, 2, 2, 4, 0, 2),    // 11: 128 x 128
     T32(4, 1, 2, 2, 4, 4, 0, 2),    // 12: 256 x 64
+#ifdef RMR_T32_ABLATE
+    // 13..25: tile 10 (256 x 96, two four-wave workgroups per CU) with parts removed; 26..: tile 1 (256 x 192)
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 1),    // 13: no MFMA
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 2),    // 14: no epilogue
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 4),    // 15: epilogue without stores
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 8),    // 16: DMAs out of range
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 16),   // 17: no fragment reads
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 10),   // 18: no epilogue, DMAs out of range
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 26),   // 19: MFMAs + barriers only
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 12),   // 20: epilogue without stores, DMAs out of range
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 32),   // 21: weight DMAs out of range
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 64),   // 22: input DMAs out of range
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 128),  // 23: no vmcnt waits in the taps
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 132),  // 24: no waits, no stores
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 130),  // 25: no waits, no epilogue
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 32),   // 26 (256 x 192)
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 64),   // 27
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 128),  // 28
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 132),  // 29
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 1),    // 30
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 2),    // 22
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 4),    // 23
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 8),    // 24
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 16),   // 25
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 26),   // 26
+#endif
 };
 constexpr int kNumT32Tiles = sizeof(kT32Tiles) / sizeof(kT32Tiles[0]);
 
 int t32_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
-int t32_lds_bytes(const T32Tile& t, int W) {
-    return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + (t.epi ? (t.threads / 64) * 32 * (t.nrep * 64 + 16) : 0);
+int t32_lds_bytes(const T32Tile& t, int W, int cout_pad) {
+    return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + (t.epi ? (t.threads / 64) * 32 * (t.nrep * 64 + 16) : 0) + cout_pad * 4;
 }
 
 }  // namespace
@@ -407,7 +464,7 @@ bool conv_t32_supported(const ConvArgs& a, int tile) {
     if (tile < 0) return true;
     const T32Tile& t = kT32Tiles[tile];
     const int na = t32_rows(t.bm, a.W) / 16;
-    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && t32_lds_bytes(t, a.W) <= 160 * 1024 / t.wgs_per_cu;
+    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && t32_lds_bytes(t, a.W, a.Cout_pad) <= 160 * 1024 / t.wgs_per_cu;
 }
 
 void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
@@ -423,7 +480,7 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
             (void)hipFuncSetAttribute((const void*)d.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int rows = t32_rows(t.bm, a.W);
-    const int lds = t32_lds_bytes(t, a.W);
+    const int lds = t32_lds_bytes(t, a.W, a.Cout_pad);
     const int n_tiles = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
     // persistent: at most wgs_per_cu workgroups per CU (a multiple of 8: a workgroup stays on its XCD), each walks tiles
     const int grid = std::min((n_tiles + 7) / 8 * 8, ctx.num_cus * t.wgs_per_cu);

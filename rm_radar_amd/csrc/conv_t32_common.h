@@ -44,82 +44,85 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (pixel = lane & 31 of fragment row i, channels 8 g + 4 (lane >> 5) + 0..3 of fragment column j).
 // EPI: 0 = results leave through v_permlane32_swap pairs as 16-byte stores (32 contiguous bytes per pixel),
 //      1 = through a per-wave LDS stage at smem + stg_base as whole rows (NREP * 64 contiguous bytes per pixel).
-template <int MREP, int NREP, int EPI>
-__device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int m0, int n0,
-                                         int wm, int wn, int lane) {
+//
+// The wide path (f16 output, 8-channel aligned views, SiLU) is written around one fact of gfx9: loads and stores
+// share vmcnt and retire in order, so a load issued behind a store cannot be waited for without waiting for the
+// store's round trip to memory.  Round 2's first version fetched the bias per channel group between the stores of
+// the groups: twelve store round trips in a row per tile, none of it overlapped with anything (measured: 110 of
+// 388 us on the 96-channel layers, the same on zeros).  Here every load of the epilogue -- the wave's bias values
+// and, with a shortcut, its residual pixels -- is issued BEFORE the first store, so there is one wait (which also
+// covers the operand DMAs already in flight for the next tile) and after it only arithmetic and stores.  Stores and
+// residual loads go through buffer resources that start at the wave's first pixel row and end at row M: rows past
+// the end are dropped / read as zero by the bounds check, no branch, and views beyond 4 GiB stay addressable.
+// BIAS_LDS: the layer's bias vector sits in LDS at smem + bias_off (Cout_pad floats, written once per kernel) and is read
+// where it is used (lgkmcnt, no registers held); otherwise the wave's values are fetched into registers up front.
+template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE>
+__device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int bias_off,
+                                              int m0, int n0, int wm, int wn, int lane) {
     constexpr int STG_PITCH = NREP * 64 + 16;   // bytes per pixel row of the epilogue stage
     const int fr = lane & 31, kq = lane >> 5;
     const int cq = kq * 4;
-    const bool wide = !a.out32 && ((a.out_cs | a.out_co) & 7) == 0;   // 16-byte stores need 8-channel alignment
+    const int mw0 = __builtin_amdgcn_readfirstlane(m0 + wm * MREP * 32);   // the wave's first pixel row
+    const int nw0 = __builtin_amdgcn_readfirstlane(n0 + wn * NREP * 32);   // and first output channel
+    const long rows_left = (long)a.M - mw0;
+    const auto view_bytes = [&](int cs) {
+        const long b = rows_left * cs * 2;
+        return (unsigned)(b <= 0 ? 0 : b > 0xfffffff0l ? 0xfffffff0l : b);
+    };
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((_Float16*)a.out + (long)mw0 * a.out_cs), 0, view_bytes(a.out_cs), 0x00020000);
+    const unsigned out_lane = (unsigned)(fr * a.out_cs + a.out_co + nw0 + kq * 8) * 2u;   // fragment row 0, channel group 0
+    // ---- every load of the epilogue, ahead of its first store ------------------------------------------------
+    float4 bias[BIAS_LDS ? 1 : NREP][BIAS_LDS ? 1 : 4];
+    if constexpr (!BIAS_LDS) {
 #pragma unroll
-    for (int i = 0; i < MREP; ++i) {
-        const int m = m0 + (wm * MREP + i) * 32 + fr;
-        if (!wide) {
-            if (m >= a.M) continue;
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[j][g] = *(const float4*)(a.bias + nw0 + j * 32 + g * 8 + cq);
+    }
+    const int bias_lane = bias_off + (nw0 + cq) * 4;
+    u32x4 rres[RES ? MREP : 1][RES ? NREP : 1][2];
+    if constexpr (RES) {
+        const __amdgpu_buffer_rsrc_t res_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)a.res + (long)mw0 * a.res_cs), 0, view_bytes(a.res_cs), 0x00020000);
+        const unsigned res_lane = (unsigned)(fr * a.res_cs + a.res_co + nw0 + kq * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
 #pragma unroll
             for (int j = 0; j < NREP; ++j)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int n = n0 + (wn * NREP + j) * 32 + gq * 8 + cq;
-                    const float4 b = *(const float4*)(a.bias + n);
-                    float v[4] = {acc[i][j][gq * 4 + 0] + b.x, acc[i][j][gq * 4 + 1] + b.y, acc[i][j][gq * 4 + 2] + b.z,
-                                  acc[i][j][gq * 4 + 3] + b.w};
-                    if (a.act) {
+                for (int gp = 0; gp < 2; ++gp)
+                    rres[i][j][gp] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_lane + (unsigned)(i * 32 * a.res_cs + j * 32 + gp * 16) * 2u, 0, 0);
+    }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = silu_t(v[r]);
-                    }
-                    if (a.res) {
-                        union {
-                            uint2 u;
-                            _Float16 h[4];
-                        } rr;
-                        rr.u = *(const uint2*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rr.h[r];
-                    }
-                    if (a.out32) {
-                        *(float4*)(a.out32 + (long)m * a.out_cs + a.out_co + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        union {
-                            uint2 u;
-                            _Float16 h[4];
-                        } o;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o.h[r] = (_Float16)v[r];
-                        *(uint2*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + n) = o.u;
-                    }
-                }
-            continue;
-        }
-        // f16 output in 16-byte pieces.  Channel groups gq and gq + 1 of a lane pair (l, l + 32) hold
-        // channels 8 gq + {0..3 | 4..7} and 8 gq + 8 + {0..3 | 4..7}: one v_permlane32_swap per dword
-        // gives the lower lane all eight channels of group gq and the upper lane those of group gq + 1.
+    for (int i = 0; i < MREP; ++i) {
+        // Channel groups gq and gq + 1 of a lane pair (l, l + 32) hold channels 8 gq + {0..3 | 4..7} and
+        // 8 gq + 8 + {0..3 | 4..7}: one v_permlane32_swap per dword gives the lower lane all eight channels of
+        // group gq and the upper lane those of group gq + 1.
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
-                const int nb = n0 + (wn * NREP + j) * 32 + gp * 16;     // first channel of the pair of groups
                 float v[8];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const float4 b = *(const float4*)(a.bias + nb + h * 8 + cq);
+                    float4 b;
+                    if constexpr (BIAS_LDS)
+                        b = *(const float4*)(smem + bias_lane + (j * 32 + (gp * 2 + h) * 8) * 4);
+                    else
+                        b = bias[j][gp * 2 + h];
                     const int r0 = (gp * 2 + h) * 4;
-                    v[h * 4 + 0] = acc[i][j][r0 + 0] + b.x;
-                    v[h * 4 + 1] = acc[i][j][r0 + 1] + b.y;
-                    v[h * 4 + 2] = acc[i][j][r0 + 2] + b.z;
-                    v[h * 4 + 3] = acc[i][j][r0 + 3] + b.w;
+                    v[h * 4 + 0] = silu_t(acc[i][j][r0 + 0] + b.x);
+                    v[h * 4 + 1] = silu_t(acc[i][j][r0 + 1] + b.y);
+                    v[h * 4 + 2] = silu_t(acc[i][j][r0 + 2] + b.z);
+                    v[h * 4 + 3] = silu_t(acc[i][j][r0 + 3] + b.w);
                 }
-                if (a.act) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = silu_t(v[r]);
-                }
-                const int nl = nb + kq * 8;   // the eight channels this lane ends up with
                 union {
-                    uint4 u;
+                    u32x4 u;
                     _Float16 h[8];
                     unsigned w[4];
                 } o;
-                if (a.res) {
+                if constexpr (RES) {
                     // the shortcut is added in f32 before the one rounding, so the values are exchanged as f32
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -128,17 +131,16 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP
                         v[4 + r] = __uint_as_float(sw[1]);
                     }
                     // lower lane: v[0..3] own group gq, v[4..7] the upper lane's group gq; upper lane: v[0..3] the lower
-                    // lane's group gq + 1, v[4..7] own -- in both cases channels nl .. nl + 7 in order
+                    // lane's group gq + 1, v[4..7] own -- in both cases its eight channels in order
                     union {
-                        uint4 u;
+                        u32x4 u;
                         _Float16 h[8];
                     } rr;
-                    if (m < a.M) rr.u = *(const uint4*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + nl);
+                    rr.u = rres[i][j][gp];
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o.h[r] = (_Float16)(v[r] + (float)rr.h[r]);
                 } else {
                     union {
-                        uint2 u;
                         _Float16 h[4];
                         unsigned w[2];
                     } lo2, hi2;
@@ -152,24 +154,89 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP
                     o.w[3] = s1[1];
                 }
                 if constexpr (EPI == 0) {
-                    if (m < a.M) *(uint4*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + nl) = o.u;
+                    if constexpr (NOSTORE)
+                        asm volatile("" : : "v"(o.u));
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(i * 32 * a.out_cs + j * 32 + gp * 16) * 2u, 0, 0);
                 } else {
-                    *(uint4*)(smem + stg_base + fr * STG_PITCH + (j * 32 + gp * 16 + kq * 8) * 2) = o.u;
+                    *(u32x4*)(smem + stg_base + fr * STG_PITCH + (j * 32 + gp * 16 + kq * 8) * 2) = o.u;
                 }
             }
         if constexpr (EPI == 1) {
             // the wave's 32 x (NREP * 32) block leaves as whole rows: NREP * 4 lanes per pixel
             constexpr int CPP = NREP * 4;   // 16-byte chunks per pixel
-            const int mb = m0 + (wm * MREP + i) * 32;
-            const int nw0 = n0 + wn * NREP * 32;
 #pragma unroll
             for (int it = 0; it < (32 * CPP) / 64; ++it) {
                 const int f = it * 64 + lane;
                 const int px = f / CPP, ch = f % CPP;
-                const uint4 vv = *(const uint4*)(smem + stg_base + px * STG_PITCH + ch * 16);
-                if (mb + px < a.M) *(uint4*)((_Float16*)a.out + (long)(mb + px) * a.out_cs + a.out_co + nw0 + ch * 8) = vv;
+                const u32x4 vv = *(const u32x4*)(smem + stg_base + px * STG_PITCH + ch * 16);
+                if constexpr (NOSTORE)
+                    asm volatile("" : : "v"(vv));
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(vv, out_rsrc, (unsigned)((i * 32 + px) * a.out_cs + a.out_co + nw0 + ch * 8) * 2u, 0, 0);
             }
         }
+    }
+}
+
+// bias_off: LDS offset of the bias vector (BIAS_LDS kernels); CAN_RES = false: the kernel's layers do not carry a
+// shortcut in the network (1x1 and strided layers, the 256-channel head tiles), so the wide shortcut path and its
+// registers are not compiled in -- a shortcut still works, through the 8-byte path below
+template <int MREP, int NREP, int EPI, bool BIAS_LDS, bool CAN_RES, bool NOSTORE = false>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int bias_off,
+                                         int m0, int n0, int wm, int wn, int lane) {
+    const int fr = lane & 31, kq = lane >> 5;
+    const int cq = kq * 4;
+    // 16-byte stores need 8-channel alignment
+    const bool wide = !a.out32 && a.act && ((a.out_cs | a.out_co) & 7) == 0 && (!a.res || (CAN_RES && ((a.res_cs | a.res_co) & 7) == 0));
+    if (wide) {
+        if constexpr (CAN_RES) {
+            if (a.res) {
+                epilogue_wide<MREP, NREP, EPI, true, BIAS_LDS, NOSTORE>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+                return;
+            }
+        }
+        epilogue_wide<MREP, NREP, EPI, false, BIAS_LDS, NOSTORE>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+        return;
+    }
+    // everything else (f32 output, no activation, 4-channel aligned views): 8-byte pieces, loads as they come
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+        const int m = m0 + (wm * MREP + i) * 32 + fr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + (wn * NREP + j) * 32 + gq * 8 + cq;
+                const float4 b = *(const float4*)(a.bias + n);
+                float v[4] = {acc[i][j][gq * 4 + 0] + b.x, acc[i][j][gq * 4 + 1] + b.y, acc[i][j][gq * 4 + 2] + b.z,
+                              acc[i][j][gq * 4 + 3] + b.w};
+                if (a.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = silu_t(v[r]);
+                }
+                if (a.res) {
+                    union {
+                        uint2 u;
+                        _Float16 h[4];
+                    } rr;
+                    rr.u = *(const uint2*)((const _Float16*)a.res + (long)m * a.res_cs + a.res_co + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rr.h[r];
+                }
+                if (a.out32) {
+                    *(float4*)(a.out32 + (long)m * a.out_cs + a.out_co + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    union {
+                        uint2 u;
+                        _Float16 h[4];
+                    } o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.h[r] = (_Float16)v[r];
+                    *(uint2*)((_Float16*)a.out + (long)m * a.out_cs + a.out_co + n) = o.u;
+                }
+            }
     }
 }
 
