@@ -56,9 +56,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 // the end are dropped / read as zero by the bounds check, no branch, and views beyond 4 GiB stay addressable.
 // BIAS_LDS: the layer's bias vector sits in LDS at smem + bias_off (Cout_pad floats, written once per kernel) and is read
 // where it is used (lgkmcnt, no registers held); otherwise the wave's values are fetched into registers up front.
-template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE>
+// SCALE (the fp8 kernel; needs BIAS_LDS): the accumulators are multiplied by one scale per output channel before the
+// bias is added; the scales are Cout_pad floats in LDS right behind the bias vector.
+template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE, bool SCALE = false>
 __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int bias_off,
                                               int m0, int n0, int wm, int wn, int lane) {
+    static_assert(!SCALE || BIAS_LDS, "scales live in LDS");
     constexpr int STG_PITCH = NREP * 64 + 16;   // bytes per pixel row of the epilogue stage
     const int fr = lane & 31, kq = lane >> 5;
     const int cq = kq * 4;
@@ -112,10 +115,18 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
                     else
                         b = bias[j][gp * 2 + h];
                     const int r0 = (gp * 2 + h) * 4;
-                    v[h * 4 + 0] = silu_t(acc[i][j][r0 + 0] + b.x);
-                    v[h * 4 + 1] = silu_t(acc[i][j][r0 + 1] + b.y);
-                    v[h * 4 + 2] = silu_t(acc[i][j][r0 + 2] + b.z);
-                    v[h * 4 + 3] = silu_t(acc[i][j][r0 + 3] + b.w);
+                    if constexpr (SCALE) {
+                        const float4 sc = *(const float4*)(smem + bias_lane + a.Cout_pad * 4 + (j * 32 + (gp * 2 + h) * 8) * 4);
+                        v[h * 4 + 0] = silu_t(acc[i][j][r0 + 0] * sc.x + b.x);
+                        v[h * 4 + 1] = silu_t(acc[i][j][r0 + 1] * sc.y + b.y);
+                        v[h * 4 + 2] = silu_t(acc[i][j][r0 + 2] * sc.z + b.z);
+                        v[h * 4 + 3] = silu_t(acc[i][j][r0 + 3] * sc.w + b.w);
+                    } else {
+                        v[h * 4 + 0] = silu_t(acc[i][j][r0 + 0] + b.x);
+                        v[h * 4 + 1] = silu_t(acc[i][j][r0 + 1] + b.y);
+                        v[h * 4 + 2] = silu_t(acc[i][j][r0 + 2] + b.z);
+                        v[h * 4 + 3] = silu_t(acc[i][j][r0 + 3] + b.w);
+                    }
                 }
                 union {
                     u32x4 u;

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "conv_igemm.h"
+#include "conv_t32_common.h"
 
 namespace rmr {
 
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int stg_base = zero_off + 1024 + wave * 32 * STG_PITCH;
+    const int bias_off = zero_off + 1024 + (EPI ? NW * 32 * STG_PITCH : 0);   // Cout_pad bias floats, then Cout_pad scales
 
     // tile vb -> (m0, n0); XCD-aware: the tiles of one XCD (vb & 7) are a contiguous range, n-tiles innermost
     const int nt_count = a.Cout_pad / BN;
@@ -129,6 +131,10 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
     const unsigned scratch = sgpr(lds0 + zero_off);
 
     if (tid < 4) *(u32x4*)(smem + zero_off + tid * 16) = u32x4{0, 0, 0, 0};
+    for (int i = tid; i < a.Cout_pad; i += NW * 64) {
+        *(float*)(smem + bias_off + i * 4) = a.bias[i];
+        *(float*)(smem + bias_off + (a.Cout_pad + i) * 4) = a.wscale[i];
+    }
 
     // byte offset of this lane's piece of input block ia of a tile whose LDS row 0 is pixel lo, channel chunk cc
     const auto in_off = [&](int lo_l, int ia, int cc) {
@@ -348,6 +354,15 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
         // The next tile's first slices and input range are in flight meanwhile.
         const int cq = kq * 4;
         const bool wide = !a.out32 && ((a.out_cs | a.out_co) & 7) == 0;   // 16-byte stores need 8-channel alignment
+        // the usual case (SiLU, no e4m3 copy of the output): the shared epilogue -- every load ahead of the first store,
+        // bias and scales from LDS (conv_t32_common.h)
+        const bool fast = wide && a.act && !a.out8 && (!a.res || (NREP < 4 && ((a.res_cs | a.res_co) & 7) == 0));
+        if (fast) {
+            if (NREP < 4 && a.res)
+                t32::epilogue_wide<MREP, NREP, EPI, (NREP < 4), true, false, true>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+            else
+                t32::epilogue_wide<MREP, NREP, EPI, false, true, false, true>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+        } else
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
             const int m = m0 + (wm * MREP + i) * 32 + fr;
@@ -563,7 +578,7 @@ const T32F8Tile kT32F8Tiles[] = {
 constexpr int kNumT32F8Tiles = sizeof(kT32F8Tiles) / sizeof(kT32F8Tiles[0]);
 
 int f8_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
-int f8_lds_bytes(const T32F8Tile& t, int W) { return 2 * f8_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024; }
+int f8_lds_bytes(const T32F8Tile& t, int W, int cout_pad) { return 2 * f8_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + cout_pad * 8; }
 
 }  // namespace
 
@@ -576,7 +591,7 @@ bool conv_t32f8_supported(const ConvArgs& a, int tile) {
     if (tile < 0) return true;
     const T32F8Tile& t = kT32F8Tiles[tile];
     const int na = f8_rows(t.bm, a.W) / 16;
-    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && f8_lds_bytes(t, a.W) <= 160 * 1024 / t.wgs_per_cu;
+    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && f8_lds_bytes(t, a.W, a.Cout_pad) <= 160 * 1024 / t.wgs_per_cu;
 }
 
 void launch_quant_f8(DeviceCtx& ctx, hipStream_t stream, const __half* in, int cs, int co, int C, unsigned char* out, int pitch, long npix) {
@@ -602,7 +617,7 @@ void launch_conv_t32f8(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile)
             (void)hipFuncSetAttribute((const void*)d.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int rows = f8_rows(t.bm, a.W);
-    const int lds = f8_lds_bytes(t, a.W);
+    const int lds = f8_lds_bytes(t, a.W, a.Cout_pad);
     const int n_tiles = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
     const int grid = std::min((n_tiles + 7) / 8 * 8, ctx.num_cus * t.wgs_per_cu);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
