@@ -46,6 +46,18 @@ class Locator {
     }
     // locate.cpp:231-264
     void cluster() noexcept { detail::check_or_abort(rmr_locator_cluster(h_)); }
+    // throughput mode (no reference counterpart): update + cluster of consecutive frames of this stream, kept as
+    // frames 0 .. n-1 for a batched search; the cluster stage runs once over all frames.  The clouds share one
+    // memory kind and point stride.
+    void updateClusterBatch(const std::vector<CloudView>& clouds) noexcept {
+        if (clouds.empty()) return;
+        std::vector<const float*> ptr;
+        std::vector<int> n;
+        for (const CloudView& c : clouds) ptr.push_back(c.xyz), n.push_back(c.size);
+        detail::check_or_abort(rmr_locator_update_cluster_batch(h_, ptr.data(), n.data(), clouds[0].stride_bytes,
+                                                                clouds[0].on_device ? RMR_MEM_DEVICE : RMR_MEM_HOST,
+                                                                (int)clouds.size()));
+    }
     // locate.cpp:323-326
     void search(std::vector<Robot>& robots) const noexcept {
         if (robots.empty()) return;

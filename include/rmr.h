@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RMR_ABI_VERSION 3
+#define RMR_ABI_VERSION 4
 
 typedef int rmr_status;
 enum {
@@ -326,6 +326,12 @@ rmr_status rmr_locator_search_kept(rmr_locator* loc, int frame, rmr_robot* robot
  * out as rmr_robot_detector_detect_batch returns them: cap per frame, counts[f] valid) */
 rmr_status rmr_locator_search_batch(rmr_locator* loc, rmr_robot* robots, const int* counts,
                                     int n_frames, int cap);
+/* throughput mode: update + cluster + keep(f) for the n_frames consecutive frames of this stream (frame f =
+ * clouds[f], n_points[f] points), with the same results -- the updates run in order (the background image and the
+ * depth queue are the stream's history, locator.h:90-91), the cluster stage (locate.cpp:231-264) as ONE pass over
+ * all frames.  Afterwards the current frame is the last one.  Needs max_frames >= n_frames. */
+rmr_status rmr_locator_update_cluster_batch(rmr_locator* loc, const float* const* clouds, const int* n_points,
+                                            int stride_bytes, int mem, int n_frames);
 
 /* private members the reference's tests reach via `#define private public`
  * (test/locate/locator_test.cpp:6-13) */

@@ -473,6 +473,32 @@ class Locator:
     def keep(self, frame: int):
         check(lib().rmr_locator_keep(self._h, frame))
 
+    def update_cluster_batch(self, clouds):
+        """Throughput mode: update + cluster + keep(f) for the consecutive frames `clouds` of this stream (all host
+        arrays or all device tensors of [n, >=3] f32 with one row stride; None / empty = the null cloud), the
+        cluster stage as one pass over all frames.  Same results as the three calls per frame."""
+        nf = len(clouds)
+        ptrs = (C.c_void_p * nf)()
+        counts = np.zeros(nf, np.int32)
+        keep_alive, stride, mem = [], 0, None
+        for f, c in enumerate(clouds):
+            if c is None or len(c) == 0:
+                ptrs[f] = None
+                continue
+            if _is_device_tensor(c):
+                if c.dim() != 2 or c.shape[1] < 3 or c.element_size() != 4 or c.stride(1) != 1:
+                    raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "device cloud must be [n, >=3] f32")
+                ptr, n, st, m = c.data_ptr(), c.shape[0], c.stride(0) * 4, _lib.MEM_DEVICE
+            else:
+                a = np.ascontiguousarray(c, np.float32)
+                keep_alive.append(a)
+                ptr, n, st, m = a.ctypes.data, a.shape[0], a.strides[0], _lib.MEM_HOST
+            if mem not in (None, m) or stride not in (0, st):
+                raise InvalidArgument(_lib.ERR_INVALID_ARGUMENT, "the clouds of a batch share one memory kind and row stride")
+            ptrs[f], counts[f], stride, mem = ptr, n, st, m
+        check(lib().rmr_locator_update_cluster_batch(self._h, ptrs, _lib.ip(counts), stride or 16,
+                                                     _lib.MEM_HOST if mem is None else mem, nf))
+
     def _search(self, robots, frame):
         n = len(robots)
         if n == 0:

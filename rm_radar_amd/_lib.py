@@ -170,6 +170,7 @@ SYMBOLS = {
     "rmr_locator_keep": (C.c_int, [_vp, C.c_int]),
     "rmr_locator_search_kept": (C.c_int, [_vp, C.c_int, _P(Robot), C.c_int]),
     "rmr_locator_search_batch": (C.c_int, [_vp, _P(Robot), _ip, C.c_int, C.c_int]),
+    "rmr_locator_update_cluster_batch": (C.c_int, [_vp, _P(_vp), _ip, C.c_int, C.c_int, C.c_int]),
     "rmr_locator_width": (C.c_int, [_vp]),
     "rmr_locator_height": (C.c_int, [_vp]),
     "rmr_locator_read_image": (C.c_int, [_vp, C.c_int, _fp]),

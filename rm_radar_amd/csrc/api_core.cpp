@@ -270,6 +270,11 @@ rmr_status rmr_locator_write_image(rmr_locator* loc, int which, const float* hos
 rmr_status rmr_locator_search_batch(rmr_locator* loc, rmr_robot* robots, const int* counts, int n_frames, int cap) {
     LOC_CALL(loc->impl.search_batch(robots, counts, n_frames, cap));
 }
+rmr_status rmr_locator_update_cluster_batch(rmr_locator* loc, const float* const* clouds, const int* n_points,
+                                            int stride_bytes, int mem, int n_frames) {
+    LOC_CALL(if (!clouds || !n_points || n_frames <= 0) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_locator_update_cluster_batch: bad arguments");
+             loc->impl.update_cluster_batch(clouds, n_points, stride_bytes, mem, n_frames));
+}
 rmr_status rmr_locator_state_bytes(const rmr_locator* loc, size_t* bytes) {
     LOC_CALL(if (!bytes) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_locator_state_bytes: null argument");
              *bytes = loc->impl.state_bytes());

@@ -27,12 +27,8 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
     std::vector<std::exception_ptr> locate_error(n_streams);
     auto locate_stream = [&](int s) {
         try {
-            for (int f = 0; f < per; ++f) {
-                const int g = s * per + f;
-                locs[s]->impl.update(clouds[g], n_points[g], stride_bytes, mem);
-                locs[s]->impl.cluster();
-                locs[s]->impl.keep(f);
-            }
+            // update + cluster + keep(f) of the stream's frames, the cluster stage batched over them (same results)
+            locs[s]->impl.update_cluster_batch(clouds + (size_t)s * per, n_points + (size_t)s * per, stride_bytes, mem, per);
         } catch (...) {
             locate_error[s] = std::current_exception();
         }

@@ -149,10 +149,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : MREP == 1 ? 4 : 2)
             for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles each
     }
 
+    const auto dma_in = [](u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+        if constexpr (ABL & 512)
+            dma16s_nt(rsrc, lds_addr, voff, soff);
+        else
+            dma16s(rsrc, lds_addr, voff, soff);
+    };
     // ---- cold start: the whole input range of chunk 0, weight slices 0 .. R-2 of the first tile -----------
     {
         const int pl0 = m0 - W - 1 + lrow;
-        for (int ia = wave; ia < na; ia += NW) dma16s(in_rsrc, sgpr(lds0 + ia * 1024), in_off(pl0, ia, 0), 0u);
+        for (int ia = wave; ia < na; ia += NW) dma_in(in_rsrc, sgpr(lds0 + ia * 1024), in_off(pl0, ia, 0), 0u);
 #pragma unroll
         for (int s = 0; s < R - 1; ++s)
             for (int q = wave; q < NB; q += NW)
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : MREP == 1 ? 4 : 2)
                             if constexpr (a_tap) {
                                     unsigned av = in_off(a_pl, ia, a_cc);
                                     asm volatile("" : "+v"(av));   // computed unconditionally: a branch around it would split the tap's basic block
-                                    dma16s(in_rsrc, sgpr(a_lds), alive ? av : OOB, 0u);
+                                    dma_in(in_rsrc, sgpr(a_lds), alive ? av : OOB, 0u);
                                 }
                         } else {
                             const bool isw = s_isw[d];
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : MREP == 1 ? 4 : 2)
 #endif
                 }
         } else {
-            epilogue<MREP, NREP, EPI, true, (NREP < 4), (ABL & 4) != 0>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+            epilogue<MREP, NREP, EPI, true, (NREP < 4), (ABL & 4) != 0, (ABL & 256) ? 2 : 0>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
         }
 
         if (!has_next) break;
@@ -434,7 +440,12 @@ const T32Tile kT32Tiles[] = {
     T32A(4, 1, 2, 3, 4, 4, 0, 2, 128),  // 23: no vmcnt waits in the taps
     T32A(4, 1, 2, 3, 4, 4, 0, 2, 132),  // 24: no waits, no stores
     T32A(4, 1, 2, 3, 4, 4, 0, 2, 130),  // 25: no waits, no epilogue
-    T32A(4, 2, 2, 3, 4, 4, 1, 1, 32),   // 26 (256 x 192)
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 256),  // 26: non-temporal stores
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 512),  // 27: non-temporal input DMAs
+    T32A(4, 1, 2, 3, 4, 4, 0, 2, 768),  // 28: both
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 256),  // 29 (256 x 192): non-temporal stores
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 768),  // 30 (256 x 192): both
+    T32A(4, 2, 2, 3, 4, 4, 1, 1, 32),   // 31 (256 x 192)
     T32A(4, 2, 2, 3, 4, 4, 1, 1, 64),   // 27
     T32A(4, 2, 2, 3, 4, 4, 1, 1, 128),  // 28
     T32A(4, 2, 2, 3, 4, 4, 1, 1, 132),  // 29

@@ -23,6 +23,14 @@ __device__ __forceinline__ void dma16s(u32x4 rsrc, unsigned lds_addr, unsigned v
                  : "memory");
 }
 
+// the same with the non-temporal hint (streamed once: do not displace what the other tiles re-read from L2)
+__device__ __forceinline__ void dma16s_nt(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
@@ -58,7 +66,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // where it is used (lgkmcnt, no registers held); otherwise the wave's values are fetched into registers up front.
 // SCALE (the fp8 kernel; needs BIAS_LDS): the accumulators are multiplied by one scale per output channel before the
 // bias is added; the scales are Cout_pad floats in LDS right behind the bias vector.
-template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE, bool SCALE = false>
+template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE, bool SCALE = false, int AUX = 0>
 __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int bias_off,
                                               int m0, int n0, int wm, int wn, int lane) {
     static_assert(!SCALE || BIAS_LDS, "scales live in LDS");
@@ -168,7 +176,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
                     if constexpr (NOSTORE)
                         asm volatile("" : : "v"(o.u));
                     else
-                        __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(i * 32 * a.out_cs + j * 32 + gp * 16) * 2u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(i * 32 * a.out_cs + j * 32 + gp * 16) * 2u, 0, AUX);
                 } else {
                     *(u32x4*)(smem + stg_base + fr * STG_PITCH + (j * 32 + gp * 16 + kq * 8) * 2) = o.u;
                 }
@@ -184,7 +192,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
                 if constexpr (NOSTORE)
                     asm volatile("" : : "v"(vv));
                 else
-                    __builtin_amdgcn_raw_buffer_store_b128(vv, out_rsrc, (unsigned)((i * 32 + px) * a.out_cs + a.out_co + nw0 + ch * 8) * 2u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(vv, out_rsrc, (unsigned)((i * 32 + px) * a.out_cs + a.out_co + nw0 + ch * 8) * 2u, 0, AUX);
             }
         }
     }
@@ -193,7 +201,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
 // bias_off: LDS offset of the bias vector (BIAS_LDS kernels); CAN_RES = false: the kernel's layers do not carry a
 // shortcut in the network (1x1 and strided layers, the 256-channel head tiles), so the wide shortcut path and its
 // registers are not compiled in -- a shortcut still works, through the 8-byte path below
-template <int MREP, int NREP, int EPI, bool BIAS_LDS, bool CAN_RES, bool NOSTORE = false>
+template <int MREP, int NREP, int EPI, bool BIAS_LDS, bool CAN_RES, bool NOSTORE = false, int AUX = 0>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int bias_off,
                                          int m0, int n0, int wm, int wn, int lane) {
     const int fr = lane & 31, kq = lane >> 5;
@@ -203,11 +211,11 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP
     if (wide) {
         if constexpr (CAN_RES) {
             if (a.res) {
-                epilogue_wide<MREP, NREP, EPI, true, BIAS_LDS, NOSTORE>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+                epilogue_wide<MREP, NREP, EPI, true, BIAS_LDS, NOSTORE, false, AUX>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
                 return;
             }
         }
-        epilogue_wide<MREP, NREP, EPI, false, BIAS_LDS, NOSTORE>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+        epilogue_wide<MREP, NREP, EPI, false, BIAS_LDS, NOSTORE, false, AUX>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
         return;
     }
     // everything else (f32 output, no activation, 4-channel aligned views): 8-byte pieces, loads as they come

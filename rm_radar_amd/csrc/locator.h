@@ -34,6 +34,8 @@ class Locator {
 
     void update(const float* xyz, int n, int stride_bytes, int mem);
     void cluster();
+    // update + cluster + keep(f) for f = 0 .. n_frames-1 (same results), the cluster stage as one pass over all frames
+    void update_cluster_batch(const float* const* clouds, const int* n_points, int stride_bytes, int mem, int n_frames);
     void search(rmr_robot* robots, int n, int slot);  // slot -1 = current frame
     // kept frames 0 .. n_frames-1 in one pass: robots[f * cap + i], i < counts[f]; one upload of the
     // rects, one launch per frame, one download, ONE synchronisation
@@ -58,6 +60,8 @@ class Locator {
     int num_clusters();
 
    private:
+    void update_into(const float* xyz, int n, int stride_bytes, int mem, float* diff_out);
+    void cluster_frames(const float* diff, int n_frames, int first_slot);
     float* image_ptr(int which);
     FrameSlot make_slot();
 
@@ -71,6 +75,7 @@ class Locator {
     // update() state
     DevBuf<unsigned long long> key_;  // per pixel (point index + 1) << 32 | depth bits
     DevBuf<float> bg_, diff_;
+    DevBuf<float> diff_batch_;        // [max_frames][npx]: the foreground images of a batch (update_cluster_batch)
     DevBuf<float> ring_;              // [queue_size][npx]
     int ring_len_ = 0, ring_head_ = 0;  // oldest slot, number of valid slots
     DevBuf<float> cloud_;             // staging for host clouds
@@ -78,7 +83,8 @@ class Locator {
 
     // cluster() scratch
     DevBuf<int> blk_count_, blk_offset_;
-    DevBuf<int> parent_, csize_, vroot_, vsize_, root_id_, counters_;
+    DevBuf<int> parent_, csize_, vroot_, vsize_, root_id_, counters_;   // counters_: [max_frames][4] + the overflow flag
+    int* overflow_ = nullptr;
     DevBuf<float> fg_depth_;  // camera depth of each foreground point (prunes the pair tests of cluster())
     DevBuf<int> store_int_;
     DevBuf<float> store_f_;

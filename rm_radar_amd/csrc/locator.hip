@@ -142,9 +142,14 @@ __global__ __launch_bounds__(256) void loc_diff(LocParams P, RingOrder order,
 
 constexpr int FG_PX_PER_BLOCK = 1024;  // 256 threads x 4 consecutive pixels
 
+// The cluster() kernels serve one frame or a batch of frames in one launch: blockIdx.y (grids over pixels or
+// points) or blockIdx.x (one workgroup per frame) is the frame; per-frame scratch lies frame-major, the
+// products go to consecutive FrameSlots (slot_int_stride ints / slot_f_stride floats apart).
 __global__ __launch_bounds__(256) void fg_count(const float* __restrict__ diff, size_t npx,
                                                 int* __restrict__ blk_count) {
     __shared__ int wsum[4];
+    diff += (size_t)blockIdx.y * npx;
+    blk_count += (size_t)blockIdx.y * gridDim.x;
     const size_t base = (size_t)blockIdx.x * FG_PX_PER_BLOCK + (size_t)threadIdx.x * 4;
     int c = 0;
 #pragma unroll
@@ -156,13 +161,19 @@ __global__ __launch_bounds__(256) void fg_count(const float* __restrict__ diff, 
     if (threadIdx.x == 0) blk_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// counters: [0] n_fg (clamped) [1] overflow flag [2] n_valid clusters
+// counters (per frame): [0] n_fg (clamped) [1] overflow flag [2] n_valid clusters.  overflow: what search() reports --
+// the current frame's flag, or (sticky: a batch of frames, cleared by the host before it) whether ANY frame overflowed
 __global__ __launch_bounds__(1024) void fg_scan(const int* __restrict__ blk_count, int nblk,
                                                 int* __restrict__ blk_offset, int max_fg,
                                                 int* __restrict__ counters,
-                                                int* __restrict__ slot_n_fg) {
+                                                int* __restrict__ slot_n_fg, long slot_int_stride,
+                                                int* __restrict__ overflow, int sticky) {
     __shared__ int wtot[16];
     __shared__ int carry;
+    blk_count += (size_t)blockIdx.x * nblk;
+    blk_offset += (size_t)blockIdx.x * nblk;
+    counters += blockIdx.x * 4;
+    slot_n_fg += blockIdx.x * slot_int_stride;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -191,6 +202,11 @@ __global__ __launch_bounds__(1024) void fg_scan(const int* __restrict__ blk_coun
         counters[0] = n > max_fg ? max_fg : n;
         counters[2] = 0;
         *slot_n_fg = counters[0];
+        if (sticky) {
+            if (n > max_fg) atomicMax(overflow, 1);
+        } else {
+            *overflow = n > max_fg ? 1 : 0;
+        }
     }
 }
 
@@ -198,8 +214,14 @@ __global__ __launch_bounds__(1024) void fg_scan(const int* __restrict__ blk_coun
 __global__ __launch_bounds__(256) void fg_compact(LocParams P, const float* __restrict__ diff,
                                                   size_t npx, const int* __restrict__ blk_offset,
                                                   int max_fg, int* __restrict__ fg_pixel,
-                                                  float* __restrict__ fg_xyz, float* __restrict__ fg_depth) {
+                                                  float* __restrict__ fg_xyz, float* __restrict__ fg_depth,
+                                                  long slot_int_stride, long slot_f_stride) {
     __shared__ int wtot[4];
+    diff += (size_t)blockIdx.y * npx;
+    blk_offset += (size_t)blockIdx.y * gridDim.x;
+    fg_pixel += blockIdx.y * slot_int_stride;
+    fg_xyz += blockIdx.y * slot_f_stride;
+    fg_depth += (size_t)blockIdx.y * max_fg;
     const size_t base = (size_t)blockIdx.x * FG_PX_PER_BLOCK + (size_t)threadIdx.x * 4;
     float val[4];
     int c = 0;
@@ -371,7 +393,9 @@ __device__ void cc_block(int n, const float* __restrict__ xyz, float tol2, int m
 // moves to global memory (L2 atomics: compare-and-swap hooks the larger root under the smaller, as in the LDS
 // forest, so the partition and its roots = lowest member index are the same) and the points spread over the
 // grid.  Both kernels return at once for a list that fits the single-workgroup path.
-__global__ __launch_bounds__(256) void cc_init_grid(const int* __restrict__ counters, int* parent, int* csize, int* root_id) {
+__global__ __launch_bounds__(256) void cc_init_grid(const int* __restrict__ counters, int* parent, int* csize, int* root_id, int max_fg) {
+    counters += blockIdx.y * 4;
+    parent += (size_t)blockIdx.y * max_fg, csize += (size_t)blockIdx.y * max_fg, root_id += (size_t)blockIdx.y * max_fg;
     const int n = counters[0];
     if (n <= CC_LDS_MAX) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -380,10 +404,15 @@ __global__ __launch_bounds__(256) void cc_init_grid(const int* __restrict__ coun
 
 __global__ __launch_bounds__(256) void cc_pairs_grid(const int* __restrict__ counters, const float* __restrict__ xyz, float tol2,
                                                       int* parent_g, const int* __restrict__ pix,
-                                                      const float* __restrict__ depth, float row_k, int wz) {
+                                                      const float* __restrict__ depth, float row_k, int wz, int max_fg,
+                                                      long slot_int_stride, long slot_f_stride) {
+    counters += blockIdx.y * 4;
     const int n = counters[0];
     if (n <= CC_LDS_MAX) return;
-    volatile int* parent = parent_g;
+    xyz += blockIdx.y * slot_f_stride;
+    pix += blockIdx.y * slot_int_stride;
+    depth += (size_t)blockIdx.y * max_fg;
+    volatile int* parent = parent_g + (size_t)blockIdx.y * max_fg;
     // a wave takes one point and spreads its candidates over the lanes: neighbouring points have neighbouring
     // candidate ranges, so the wave's loads are the same few cache lines
     const int lane = threadIdx.x & 63;
@@ -433,9 +462,18 @@ __global__ __launch_bounds__(CC_THREADS) void cc_fused(int* __restrict__ counter
                                                        int* g_vsize, int* __restrict__ fg_cluster,
                                                        int* __restrict__ slot_n_clusters,
                                                        const int* __restrict__ fg_pixel,
-                                                       const float* __restrict__ fg_depth, float row_k, int wz) {
+                                                       const float* __restrict__ fg_depth, float row_k, int wz, int max_fg,
+                                                       long slot_int_stride, long slot_f_stride) {
     extern __shared__ __attribute__((aligned(16))) int cc_lds[];
     __shared__ int nvalid;
+    {
+        const size_t f = blockIdx.x, fo = f * (size_t)max_fg;
+        counters += f * 4;
+        xyz += f * slot_f_stride;
+        fg_cluster += f * slot_int_stride, slot_n_clusters += f * slot_int_stride, fg_pixel += f * slot_int_stride;
+        fg_depth += fo;
+        g_parent += fo, g_csize += fo, g_root_id += fo, g_vroot += fo, g_vsize += fo;
+    }
     const int n = counters[0];
     if (n <= CC_LDS_MAX) {
         int* parent = cc_lds;                    // [CC_LDS_MAX]
@@ -708,16 +746,21 @@ Locator::Locator(const rmr_locator_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg.de
     cloud_pin_.alloc((size_t)cfg_.max_points * 4);
 
     const int nblk = (int)((npx_ + FG_PX_PER_BLOCK - 1) / FG_PX_PER_BLOCK);
-    blk_count_.alloc(nblk);
-    blk_offset_.alloc(nblk);
-    parent_.alloc(mf);
-    fg_depth_.alloc(mf);
-    csize_.alloc(mf);
-    vroot_.alloc(mf);
-    vsize_.alloc(mf);
-    root_id_.alloc(mf);
-    counters_.alloc(4);
-    RMR_HIP(hipMemsetAsync(counters_.p, 0, 4 * sizeof(int), stream_));
+    // cluster() scratch, one set per frame of a batch (update_cluster_batch runs max_frames frames in one launch each)
+    const size_t bf = (size_t)cfg_.max_frames;
+    blk_count_.alloc(bf * nblk);
+    blk_offset_.alloc(bf * nblk);
+    fg_depth_.alloc(bf * mf);
+    // the global union-find forest is only touched by lists beyond CC_LDS_MAX points
+    const size_t forest = mf > CC_LDS_MAX ? bf * mf : (size_t)mf;
+    parent_.alloc(forest);
+    csize_.alloc(forest);
+    vroot_.alloc(forest);
+    vsize_.alloc(forest);
+    root_id_.alloc(forest);
+    counters_.alloc(4 * bf + 1);
+    RMR_HIP(hipMemsetAsync(counters_.p, 0, (4 * bf + 1) * sizeof(int), stream_));
+    overflow_ = counters_.p + 4 * bf;
 
     const int nslots = 1 + cfg_.max_frames;
     slot_ints_.alloc((size_t)nslots * (2 + 2 * (size_t)mf));
@@ -748,11 +791,13 @@ Locator::~Locator() {
 }
 
 // locate.cpp:158-220
-void Locator::update(const float* xyz, int n, int stride_bytes, int mem) {
+void Locator::update(const float* xyz, int n, int stride_bytes, int mem) { update_into(xyz, n, stride_bytes, mem, diff_.p); }
+
+void Locator::update_into(const float* xyz, int n, int stride_bytes, int mem, float* diff_out) {
     ctx_.use();
     if (!xyz || n <= 0) {
         // locate.cpp:160-171: depth and diff cleared, nothing queued
-        RMR_HIP(hipMemsetAsync(diff_.p, 0, npx_ * sizeof(float), stream_));
+        RMR_HIP(hipMemsetAsync(diff_out, 0, npx_ * sizeof(float), stream_));
         return;
     }
     if (stride_bytes < 12 || (stride_bytes & 3))
@@ -794,7 +839,7 @@ void Locator::update(const float* xyz, int n, int stride_bytes, int mem) {
     for (int i = 0; i < ring_len_; ++i) order.slot[i] = (ring_head_ + i) % Q;
     {
         ProfScope ps(ctx_.prof, stream_, "loc_diff", 0, (double)npx_ * (8 + 4 * (ring_len_ + 2)));
-        loc_diff<<<(unsigned)((npx_ + 255) / 256), 256, 0, stream_>>>(prm_, order, key_.p, bg_.p, ring_.p, diff_.p, npx_);
+        loc_diff<<<(unsigned)((npx_ + 255) / 256), 256, 0, stream_>>>(prm_, order, key_.p, bg_.p, ring_.p, diff_out, npx_);
         RMR_HIP(hipGetLastError());
     }
 }
@@ -825,16 +870,24 @@ static double min_singular3(const float* m) {
     return std::sqrt(std::max(e_min, 0.0)) * 0.999;
 }
 
-void Locator::cluster() {
+void Locator::cluster() { cluster_frames(diff_.p, 1, 0); }
+
+// The frames' foreground images lie npx_ floats apart from `diff`; their products go to slots first_slot, first_slot + 1, ...
+// Every kernel takes the frame from its block index, so a batch costs the launches of one frame.
+void Locator::cluster_frames(const float* diff, int n_frames, int first_slot) {
     ctx_.use();
     const int mf = cfg_.max_foreground;
     const int nblk = (int)((npx_ + FG_PX_PER_BLOCK - 1) / FG_PX_PER_BLOCK);
     const int gfg = (mf + 255) / 256;
-    FrameSlot& cur = slots_[0];
-    ProfScope ps(ctx_.prof, stream_, "loc_cluster", 0, (double)npx_ * 8);
-    fg_count<<<nblk, 256, 0, stream_>>>(diff_.p, npx_, blk_count_.p);
-    fg_scan<<<1, 1024, 0, stream_>>>(blk_count_.p, nblk, blk_offset_.p, mf, counters_.p, cur.n_fg);
-    fg_compact<<<nblk, 256, 0, stream_>>>(prm_, diff_.p, npx_, blk_offset_.p, mf, cur.fg_pixel, cur.fg_xyz, fg_depth_.p);
+    const unsigned F = (unsigned)n_frames;
+    const long sis = 2 + 2 * (long)mf, sfs = 3 * (long)mf;   // ints / floats from one FrameSlot to the next
+    FrameSlot& cur = slots_[first_slot];
+    ProfScope ps(ctx_.prof, stream_, "loc_cluster", 0, (double)npx_ * 8 * n_frames);
+    const int sticky = n_frames > 1;
+    if (sticky) RMR_HIP(hipMemsetAsync(overflow_, 0, sizeof(int), stream_));
+    fg_count<<<dim3(nblk, F), 256, 0, stream_>>>(diff, npx_, blk_count_.p);
+    fg_scan<<<F, 1024, 0, stream_>>>(blk_count_.p, nblk, blk_offset_.p, mf, counters_.p, cur.n_fg, sis, overflow_, sticky);
+    fg_compact<<<dim3(nblk, F), 256, 0, stream_>>>(prm_, diff, npx_, blk_offset_.p, mf, cur.fg_pixel, cur.fg_xyz, fg_depth_.p, sis, sfs);
     static std::once_flag once;
     std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)cc_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * CC_LDS_MAX * 4);
@@ -849,13 +902,38 @@ void Locator::cluster() {
         row_k = (float)(prm_.zoom * fy * std::sqrt(prm_.tol2) / s_min * (1.f + t_max) * 1.001);
     }
     if (mf > CC_LDS_MAX) {   // lists that can outgrow the single-workgroup forest: pair phase over the chip
-        cc_init_grid<<<gfg, 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p, root_id_.p);
-        cc_pairs_grid<<<std::min(gfg * 4, 4 * ctx_.num_cus), 256, 0, stream_>>>(counters_.p, cur.fg_xyz, prm_.tol2, parent_.p, cur.fg_pixel,
-                                                                             fg_depth_.p, row_k, prm_.wz);
+        cc_init_grid<<<dim3(gfg, F), 256, 0, stream_>>>(counters_.p, parent_.p, csize_.p, root_id_.p, mf);
+        // a frame's pair phase gets the whole chip when it is alone, its share of it in a batch (the kernel strides)
+        const int pw = std::max(8, std::min(gfg * 4, 4 * ctx_.num_cus) / n_frames);
+        cc_pairs_grid<<<dim3(pw, F), 256, 0, stream_>>>(counters_.p, cur.fg_xyz, prm_.tol2, parent_.p, cur.fg_pixel, fg_depth_.p, row_k,
+                                                       prm_.wz, mf, sis, sfs);
     }
-    cc_fused<<<1, CC_THREADS, 9 * CC_LDS_MAX * sizeof(int), stream_>>>(
+    cc_fused<<<F, CC_THREADS, 9 * CC_LDS_MAX * sizeof(int), stream_>>>(
         counters_.p, cur.fg_xyz, prm_.tol2, prm_.min_cluster, prm_.max_cluster, parent_.p, csize_.p, root_id_.p,
-        vroot_.p, vsize_.p, cur.fg_cluster, cur.n_clusters, cur.fg_pixel, fg_depth_.p, row_k, prm_.wz);
+        vroot_.p, vsize_.p, cur.fg_cluster, cur.n_clusters, cur.fg_pixel, fg_depth_.p, row_k, prm_.wz, mf, sis, sfs);
+    RMR_HIP(hipGetLastError());
+}
+
+// update + cluster + keep(f) of n_frames consecutive frames of this stream.  The updates stay one after another (the
+// background image and the depth ring are the stream's history), each leaving its foreground image in its own slice
+// of diff_batch_; then ONE cluster pass over all frames writes the kept slots 0 .. n_frames-1 directly.  Per frame
+// the same kernels see the same inputs as update(); cluster(); keep(f), so the results are the same bits -- but a
+// 64-frame batch is 2 x 64 + 8 launches instead of 7 x 64, and the single-workgroup connected-components stage runs
+// as one 64-workgroup launch instead of 64 launches that each hold a CU for ~0.1 ms beside the detector's kernels.
+void Locator::update_cluster_batch(const float* const* clouds, const int* n_points, int stride_bytes, int mem, int n_frames) {
+    ctx_.use();
+    if (n_frames <= 0) return;
+    if (n_frames > cfg_.max_frames)
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator: a batch of %d frames exceeds max_frames=%d", n_frames, cfg_.max_frames);
+    if (diff_batch_.n < (size_t)n_frames * npx_) diff_batch_.alloc((size_t)cfg_.max_frames * npx_);
+    for (int f = 0; f < n_frames; ++f) update_into(clouds[f], n_points[f], stride_bytes, mem, diff_batch_.p + (size_t)f * npx_);
+    cluster_frames(diff_batch_.p, n_frames, 1);
+    // "the current frame" (read_image, foreground(), search(slot -1)) is the batch's last one
+    RMR_HIP(hipMemcpyAsync(diff_.p, diff_batch_.p + (size_t)(n_frames - 1) * npx_, npx_ * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+    const FrameSlot& s = slots_[n_frames];
+    const FrameSlot& d = slots_[0];
+    slot_copy<<<(cfg_.max_foreground + 255) / 256, 256, 0, stream_>>>(
+        s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz, s.fg_cluster, d.n_fg, d.n_clusters, d.fg_pixel, d.fg_xyz, d.fg_cluster);
     RMR_HIP(hipGetLastError());
 }
 
@@ -918,7 +996,7 @@ void Locator::search(rmr_robot* robots, int n, int slot) {
     }
     RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, stream_));
     int flags[2] = {0, 0};
-    RMR_HIP(hipMemcpyAsync(flags, counters_.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipMemcpyAsync(flags, overflow_, sizeof(int), hipMemcpyDeviceToHost, stream_));
     RMR_HIP(hipStreamSynchronize(stream_));
     for (int i = 0; i < n; ++i) {
         const float* o = loc_pin_.p + 4 * i;
@@ -980,7 +1058,7 @@ void Locator::search_batch_begin(const rmr_robot* robots, const int* counts, int
     }
     RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * total, hipMemcpyDeviceToHost, stream_));
     search_flags_.p[0] = 0;
-    RMR_HIP(hipMemcpyAsync(search_flags_.p, counters_.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipMemcpyAsync(search_flags_.p, overflow_, sizeof(int), hipMemcpyDeviceToHost, stream_));
 }
 
 void Locator::search_batch_end(rmr_robot* robots, const int* counts, int n_frames, int cap) {

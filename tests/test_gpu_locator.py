@@ -285,6 +285,68 @@ def test_search_batch_equals_per_frame_search(rmr):
         loc.search_batch_raw(a, np.array([cap + 1] * nf, np.int32), cap)
 
 
+@pytest.mark.parametrize("max_fg", [4096, 32768])
+def test_update_cluster_batch_equals_per_frame_calls(rmr, max_fg):
+    # throughput mode: one cluster pass over a batch of frames == update(); cluster(); keep(f) frame by frame, bit for bit
+    # (max_fg 4096: the single-workgroup forest only; 32768: the grid kernels of the large-list path are launched too)
+    import ctypes as C
+    import torch
+    from rm_radar_amd import _lib
+    size, nf, cap = (640, 640), 7, 3
+    eye = np.eye(4, dtype=np.float32)
+    rects = [[(100, 300, 120, 90), (400, 200, 80, 120), (10, 10, 30, 30)][: (f + 1) % 4] for f in range(nf)]
+    for device_clouds in (False, True):
+        rng = np.random.default_rng(33)
+        first = scenes.make_cloud(rng, 30000, scenes.K640, scenes.SAMPLE_L2C, size)
+        clouds = [scenes.make_cloud(rng, 20000, scenes.K640, scenes.SAMPLE_L2C, size, [(r, 2000.0 + 100 * f, 250) for r in rects[f][:2]])
+                  for f in range(nf)]
+        clouds[3] = None   # a null cloud inside the batch: that frame's foreground is empty, nothing is queued
+        if device_clouds:
+            clouds = [None if c is None else torch.from_numpy(np.ascontiguousarray(c, np.float32)).cuda() for c in clouds]
+        a = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, eye, max_frames=nf, max_foreground=max_fg)
+        b = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, eye, max_frames=nf, max_foreground=max_fg)
+        a.update(first)
+        b.update(first)
+        for f in range(nf):
+            a.update(clouds[f])
+            a.cluster()
+            a.keep(f)
+        b.update_cluster_batch(clouds)
+        for which in (a.DIFF, a.BACKGROUND, a.DEPTH):
+            assert np.array_equal(a.read_image(which), b.read_image(which))
+        for x, y in zip(a.foreground(), b.foreground()):   # the current frame is the batch's last one
+            assert np.array_equal(x, y)
+        assert a.num_clusters == b.num_clusters
+        def fill():
+            arr = (_lib.Robot * (nf * cap))()
+            for f in range(nf):
+                for i, r in enumerate(rects[f]):
+                    arr[f * cap + i].rect[:] = [float(v) for v in r]
+            return arr
+        counts = np.array([len(r) for r in rects], np.int32)
+        ra, rb = fill(), fill()
+        a.search_batch_raw(ra, counts, cap)
+        b.search_batch_raw(rb, counts, cap)
+        located = 0
+        for k in range(nf * cap):
+            assert ra[k].has_location == rb[k].has_location and tuple(ra[k].location) == tuple(rb[k].location)
+            located += ra[k].has_location
+        assert located >= 5
+        # the stream goes on after a batch exactly as after the per-frame calls
+        nxt = scenes.make_cloud(rng, 20000, scenes.K640, scenes.SAMPLE_L2C, size, [(rects[0][0], 2500.0, 300)])
+        for loc in (a, b):
+            loc.update(nxt)
+            loc.cluster()
+        assert np.array_equal(a.read_image(a.DIFF), b.read_image(b.DIFF))
+        for x, y in zip(a.foreground(), b.foreground()):
+            assert np.array_equal(x, y)
+        a.close()
+        b.close()
+    loc = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, eye, max_frames=2)
+    with pytest.raises(rmr.InvalidArgument):
+        loc.update_cluster_batch([first, first, first])   # more frames than max_frames
+
+
 def test_dense_foreground_beyond_one_workgroup(rmr, oracle):
     """K = 20 robots of ~600 points (kMaxBatchSize cars, sample_radar.h:34): more than 4096 foreground points,
     so the pair phase of the clustering runs over the whole chip on a global union-find forest (cc_init_grid /
