@@ -530,9 +530,16 @@ __global__ __launch_bounds__(256) void loc_search(LocParams P, const int* __rest
                                                   const float* __restrict__ fg_xyz,
                                                   const int* __restrict__ fg_cluster,
                                                   const int* __restrict__ rects,
-                                                  float* __restrict__ out, int max_buckets) {
+                                                  float* __restrict__ out, int max_buckets,
+                                                  const int* __restrict__ robot_frame, long slot_int_stride, long slot_f_stride) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     int* cnt = smem;  // [max_buckets] bucket b = cluster id b-1
+    if (robot_frame) {   // a batch over kept frames: this robot's frame selects the FrameSlot (consecutive slots)
+        const long f = robot_frame[blockIdx.x];
+        n_fg_p += f * slot_int_stride, n_cl_p += f * slot_int_stride;
+        fg_pixel += f * slot_int_stride, fg_cluster += f * slot_int_stride;
+        fg_xyz += f * slot_f_stride;
+    }
     __shared__ int red_cnt[4], red_key[4];
     __shared__ double red_s[4][3];
     __shared__ int win_key, win_cnt;
@@ -991,7 +998,7 @@ void Locator::search(rmr_robot* robots, int n, int slot) {
         ProfScope ps(ctx_.prof, stream_, "loc_search", 0, 0);
         const int nbuckets = max_clusters_ + 1;
         loc_search<<<n, 256, nbuckets * sizeof(int), stream_>>>(prm_, f.n_fg, f.n_clusters, f.fg_pixel, f.fg_xyz,
-                                                                f.fg_cluster, rects_dev_.p, loc_dev_.p, nbuckets);
+                                                                f.fg_cluster, rects_dev_.p, loc_dev_.p, nbuckets, nullptr, 0, 0);
         RMR_HIP(hipGetLastError());
     }
     RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, stream_));
@@ -1031,9 +1038,10 @@ void Locator::search_batch_begin(const rmr_robot* robots, const int* counts, int
     if (n_frames <= 0) return;
     const int total = checked_total(robots, counts, n_frames, cap, cfg_.max_frames);
     if (total == 0) return;
-    rects_pin_.ensure((size_t)4 * total);
+    // staging: 4 ints of zoomed rect per robot, then one int per robot: the kept frame it belongs to
+    rects_pin_.ensure((size_t)5 * total);
     loc_pin_.ensure((size_t)4 * total);
-    rects_dev_.ensure((size_t)4 * total);
+    rects_dev_.ensure((size_t)5 * total);
     loc_dev_.ensure((size_t)4 * total);
     search_flags_.ensure(2);
     int at = 0;
@@ -1042,19 +1050,19 @@ void Locator::search_batch_begin(const rmr_robot* robots, const int* counts, int
             const rmr_robot& r = robots[(size_t)f * cap + i];
             const int ri[4] = {cv_round(r.rect[0]), cv_round(r.rect[1]), cv_round(r.rect[2]), cv_round(r.rect[3])};
             zoom(ri, rects_pin_.p + 4 * at);
+            rects_pin_.p[4 * total + at] = f;
         }
-    RMR_HIP(hipMemcpyAsync(rects_dev_.p, rects_pin_.p, sizeof(int) * 4 * total, hipMemcpyHostToDevice, stream_));
+    RMR_HIP(hipMemcpyAsync(rects_dev_.p, rects_pin_.p, sizeof(int) * 5 * total, hipMemcpyHostToDevice, stream_));
     const int nbuckets = max_clusters_ + 1;
-    at = 0;
-    for (int f = 0; f < n_frames; ++f) {
-        if (!counts[f]) continue;
-        const FrameSlot& s = slots_[f + 1];
+    {
+        // ONE launch over the robots of all frames (a workgroup per robot, as in search())
+        const FrameSlot& s = slots_[1];
+        const long mf = cfg_.max_foreground;
         ProfScope ps(ctx_.prof, stream_, "loc_search", 0, 0);
-        loc_search<<<counts[f], 256, nbuckets * sizeof(int), stream_>>>(prm_, s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz,
-                                                                        s.fg_cluster, rects_dev_.p + 4 * at,
-                                                                        loc_dev_.p + 4 * at, nbuckets);
+        loc_search<<<total, 256, nbuckets * sizeof(int), stream_>>>(prm_, s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz, s.fg_cluster,
+                                                                    rects_dev_.p, loc_dev_.p, nbuckets, rects_dev_.p + 4 * total,
+                                                                    2 + 2 * mf, 3 * mf);
         RMR_HIP(hipGetLastError());
-        at += counts[f];
     }
     RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * total, hipMemcpyDeviceToHost, stream_));
     search_flags_.p[0] = 0;
