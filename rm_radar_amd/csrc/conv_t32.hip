@@ -52,7 +52,7 @@ using namespace t32;
 // ABL (development builds only, -DRMR_T32_ABLATE): bit 0 = no MFMAs, 1 = no epilogue, 2 = epilogue without stores,
 // 3 = every DMA out of range (zeros arrive, no memory traffic), 4 = no fragment reads in the K loop.  Timing only.
 template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI, int ABL = 0>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : MREP == 1 ? 4 : 2)) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
+__global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 2 : MREP == 1 ? 4 : 2)) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 32;
     constexpr int BN = WN * NREP * 32;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : MREP == 1 ? 4 : 2)
 #endif
                 }
         } else {
-            epilogue<MREP, NREP, EPI, true, (NREP < 4), (ABL & 4) != 0, (ABL & 256) ? 2 : 0>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+            epilogue<MREP, NREP, EPI, true, (NREP < 4 && MREP * NREP <= 8), (ABL & 4) != 0, (ABL & 256) ? 2 : 0>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
         }
 
         if (!has_next) break;
@@ -425,6 +425,9 @@ const T32Tile kT32Tiles[] = {
     T32(4, 1, 2, 3, 4, 4, 0, 2),    // 10: 256 x 96
     T32(2, 2, 2, 2, 2, 4, 0, 2),    // 11: 128 x 128
     T32(4, 1, 2, 2, 4, 4, 0, 2),    // 12: 256 x 64
+    // (tried: ONE four-wave workgroup per CU with a 128 x 96 wave tile, T32(2, 2, 4, 3, 4, 5, 0, 1) -- 192 accumulators, 7
+    // fragment reads per 12 MFMAs instead of 10, one wave per SIMD: 304.4 us against 303.1 on M409600 N192 K1728.  Half the
+    // waves, 30 % fewer LDS reads, the same time: the K loop sits at the package power limit, not at a pipe.)
 #ifdef RMR_T32_ABLATE
     // 13..25: tile 10 (256 x 96, two four-wave workgroups per CU) with parts removed; 26..: tile 1 (256 x 192)
     T32A(4, 1, 2, 3, 4, 4, 0, 2, 1),    // 13: no MFMA
