@@ -71,8 +71,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
     constexpr int STAGE_BYTES = PW_SPS * SSB;
     constexpr int NINST = STAGE_BYTES / 1024; // DMA instructions per stage
     constexpr int NI = NINST / NW;            // per wave
-    constexpr int NST = MREP * PW_NREP;       // stores per wave per epilogue
     constexpr bool OUT32 = MODE == 1, PRE = MODE == 2;
+    // stores per wave per epilogue: f32 results leave as one 16-byte store per 16 x 16 tile; f16 results are first
+    // exchanged between lane rows (v_permlane16_swap) so that a lane holds 8 consecutive channels: two tiles per store
+    constexpr int NST = OUT32 ? MREP * PW_NREP : MREP + MREP / 2;
+    static_assert(MREP % 2 == 0 && PW_NREP == 3, "the f16 store pairing assumes three channel tiles and an even MREP");
     static_assert(KS % PW_SPS == 0 && NINST % NW == 0, "stage geometry");
     static_assert(STAGES >= 2 && STAGES <= 4 && E <= 8, "ring depth / stages per block");
 
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
 #pragma unroll
                         for (int j = 0; j < PW_NREP; ++j) asm volatile("" : "+v"(tpre[i][j]));  // uses stay below the wait
                 }
+                u32x2 packed[MREP][PW_NREP];
 #pragma unroll
                 for (int i = 0; i < MREP; ++i) {
                     const int m = m0 + (wm * MREP + i) * 16 + px;
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = silu_p(v[e]);
                         }
-                        const unsigned off = (rowoff + (unsigned)(j * 16) * elt) | dead;
                         if (OUT32) {
+                            const unsigned off = (rowoff + (unsigned)(j * 16) * elt) | dead;
                             u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                             __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
                         } else {
@@ -284,9 +288,39 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
                             } o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o.h[e] = (_Float16)v[e];
-                            __builtin_amdgcn_raw_buffer_store_b64(o.u, out_rsrc, off, 0, 0);
+                            packed[i][j] = o.u;
                         }
                         acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if (!OUT32) {
+                    // A lane of row r = lane / 16 holds channels 4 r .. 4 r + 3 of every 16-channel tile.  v_permlane16_swap
+                    // exchanges the odd rows of its first operand with the even rows of its second: on tiles A and B it
+                    // leaves rows 0 / 2 with channels 0..7 / 8..15 of A and rows 1 / 3 with those of B -- one 16-byte
+                    // store per lane for two tiles (64 contiguous bytes per pixel where A and B are neighbours).
+                    const int lrow = lane >> 4;
+                    const auto swap2 = [](u32x2 A, u32x2 B) {
+                        const auto lo = __builtin_amdgcn_permlane16_swap(A.x, B.x, false, false);
+                        const auto hi = __builtin_amdgcn_permlane16_swap(A.y, B.y, false, false);
+                        return u32x4{lo[0], hi[0], lo[1], hi[1]};
+                    };
+                    // byte offset of channel 0 of the wave's tile 0 (obase carries this lane's 4 r as well)
+                    const unsigned obase0 = obase - (unsigned)(lrow * 4) * 2u;
+#pragma unroll
+                    for (int i = 0; i < MREP; ++i) {
+                        // tiles 0 and 1 of pixel block i: rows 0 / 2 store into tile 0, rows 1 / 3 into tile 1
+                        const int m = m0 + (wm * MREP + i) * 16 + px;
+                        const unsigned dead = m < a.M ? 0u : 0xffffffffu;
+                        const unsigned off = (unsigned)(m * a.out_cs) * 2u + obase0 + (unsigned)((lrow & 1) * 16 + (lrow >> 1) * 8) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b128(swap2(packed[i][0], packed[i][1]), out_rsrc, off | dead, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MREP; i += 2) {
+                        // tile 2 of pixel blocks i and i + 1: rows 0 / 2 store block i's pixel, rows 1 / 3 block i + 1's
+                        const int m = m0 + (wm * MREP + i + (lrow & 1)) * 16 + px;
+                        const unsigned dead = m < a.M ? 0u : 0xffffffffu;
+                        const unsigned off = (unsigned)(m * a.out_cs) * 2u + obase0 + (unsigned)(32 + (lrow >> 1) * 8) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b128(swap2(packed[i][2], packed[i + 1][2]), out_rsrc, off | dead, 0, 0);
                     }
                 }
             }
