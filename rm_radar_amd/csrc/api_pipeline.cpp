@@ -2,6 +2,9 @@
 // per frame (samples/sample_radar.h:106-127: update + cluster on one thread while detect runs on
 // another, join, search), over a batch of frames of one camera / LiDAR stream -- or of several streams that
 // share the GPU and its detector, each with its own Locator.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <exception>
 #include <thread>
 #include <vector>
@@ -21,6 +24,14 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
     for (int s = 0; s < n_streams; ++s)
         if (!locs[s]) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_pipeline_run: null locator");
     const int per = n_frames / n_streams;
+    // RMR_STEP_TIMING=1: host-side timeline of a call on stderr (where the time between two steps goes)
+    static const bool timing = std::getenv("RMR_STEP_TIMING") != nullptr;
+    static std::chrono::steady_clock::time_point last_exit;
+    const auto t_in = std::chrono::steady_clock::now();
+    const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
+    };
+    std::chrono::steady_clock::time_point t_cars = t_in, t_cars_done = t_in, t_det = t_in, t_search = t_in;
     // threads A: a Locator carries temporal state, so the frames of a stream go in order, one helper thread per
     // stream (each Locator enqueues on its own HIP stream); a frame's foreground list is kept in slot f of its
     // stream for the batched search
@@ -55,6 +66,7 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
     std::vector<int> car_counts(n_frames, 0), car_index((size_t)n_frames * cap, -1);
     bool searching = false;
     auto after_cars = [&](const std::vector<std::vector<rmr_detection>>& cars) {
+        t_cars = std::chrono::steady_clock::now();
         join_all();
         if (any_locate_error()) return;
         for (int f = 0; f < n_frames; ++f) {
@@ -67,6 +79,7 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
         for (int s = 0; s < n_streams; ++s)
             locs[s]->impl.search_batch_begin(car_robots.data() + (size_t)s * per * stride, car_counts.data() + s * per, per, stride);
         searching = true;
+        t_cars_done = std::chrono::steady_clock::now();
     };
     std::exception_ptr detect_error;
     try {
@@ -74,12 +87,14 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
     } catch (...) {
         detect_error = std::current_exception();
     }
+    t_det = std::chrono::steady_clock::now();
     join_all();
     if (detect_error) std::rethrow_exception(detect_error);
     if (auto e = any_locate_error()) std::rethrow_exception(e);
     if (searching)
         for (int s = 0; s < n_streams; ++s)
             locs[s]->impl.search_batch_end(car_robots.data() + (size_t)s * per * stride, car_counts.data() + s * per, per, stride);
+    t_search = std::chrono::steady_clock::now();
     for (int f = 0; f < n_frames; ++f)
         for (int i = 0; i < std::min(n_out[f], cap); ++i) {
             const int c = car_index[(size_t)f * cap + i];
@@ -88,6 +103,12 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
             rmr_robot& dst = out[(size_t)f * cap + i];
             if (src.has_location) dst.has_location = 1, std::copy(src.location, src.location + 3, dst.location);
         }
+    if (timing) {
+        const auto t_out = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rmr step] since last exit %ld us | entry -> cars known %ld | after_cars %ld | armor stage + assembly %ld | search end %ld | merge %ld\n",
+                     us(last_exit, t_in), us(t_in, t_cars), us(t_cars, t_cars_done), us(t_cars_done, t_det), us(t_det, t_search), us(t_search, t_out));
+        last_exit = t_out;
+    }
 }
 
 extern "C" rmr_status rmr_pipeline_run_batch(rmr_robot_detector* rd, rmr_locator* loc, const rmr_image* imgs,

@@ -78,9 +78,10 @@ Detector::Detector(const rmr_detector_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg
     post_scratch_.alloc(postprocess_scratch_bytes(B, net_->anchors()));
     det_cap_ = net_->anchors();  // every anchor can survive, as in the reference (detector.cu:549)
     dets_dev_.alloc((size_t)B * det_cap_);
-    dets_pin_.alloc((size_t)B * kHeadRows);
+    // [B][kHeadRows] rows, then B counts: one contiguous block on both sides
+    heads_dev_.alloc((size_t)B * kHeadRows * sizeof(rmr_detection) + (size_t)B * sizeof(int));
+    heads_pin_.alloc(heads_dev_.n);
     counts_dev_.alloc(B);
-    counts_pin_.alloc(B);
 }
 
 Detector::~Detector() {
@@ -114,13 +115,12 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
     launch_postprocess(ctx_, stream_, net_->output(), n, net_->channels(), net_->anchors(), net_->nc(),
                        cfg_.nms_thresh, cfg_.conf_thresh, pp_dev_.p, post_scratch_.p, dets_dev_.p,
                        counts_dev_.p, det_cap_);
-    // D2H: the counts plus the first kHeadRows rows of every image in one strided copy (the
-    // reference copies all 8400 rows of every image, detector.cu:549-551); images with more
-    // survivors are topped up after the sync in detect_staged()
-    RMR_HIP(hipMemcpyAsync(counts_pin_.p, counts_dev_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    RMR_HIP(hipMemcpy2DAsync(dets_pin_.p, kHeadRows * sizeof(rmr_detection), dets_dev_.p,
-                             (size_t)det_cap_ * sizeof(rmr_detection), kHeadRows * sizeof(rmr_detection), n,
-                             hipMemcpyDeviceToHost, stream_));
+    // D2H: the first kHeadRows rows of every image and the counts, gathered on the device into one block and fetched
+    // with ONE contiguous copy (the reference copies all 8400 rows of every image, detector.cu:549-551); images with
+    // more survivors are topped up after the sync in detect_staged()
+    launch_gather_heads(stream_, dets_dev_.p, counts_dev_.p, det_cap_, kHeadRows, n, heads_dev_.p);
+    RMR_HIP(hipMemcpyAsync(heads_pin_.p, heads_dev_.p, (size_t)n * kHeadRows * sizeof(rmr_detection) + (size_t)n * sizeof(int),
+                           hipMemcpyDeviceToHost, stream_));
 }
 
 void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out) {
@@ -130,11 +130,12 @@ void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std:
     enqueue(descs, true);
     RMR_HIP(hipStreamSynchronize(stream_));
     bool extra = false;
+    const rmr_detection* rows = (const rmr_detection*)heads_pin_.p;
+    const int* counts = (const int*)(heads_pin_.p + (size_t)n * kHeadRows * sizeof(rmr_detection));
     for (int i = 0; i < n; ++i) {
-        const int c = counts_pin_.p[i];
+        const int c = counts[i];
         out[i].resize(c);
-        std::copy(dets_pin_.p + (size_t)i * kHeadRows, dets_pin_.p + (size_t)i * kHeadRows + std::min(c, kHeadRows),
-                  out[i].begin());
+        std::copy(rows + (size_t)i * kHeadRows, rows + (size_t)i * kHeadRows + std::min(c, kHeadRows), out[i].begin());
         if (c > kHeadRows) {
             RMR_HIP(hipMemcpyAsync(out[i].data() + kHeadRows, dets_dev_.p + (size_t)i * det_cap_ + kHeadRows,
                                    (size_t)(c - kHeadRows) * sizeof(rmr_detection), hipMemcpyDeviceToHost, stream_));

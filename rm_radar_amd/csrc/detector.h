@@ -61,8 +61,8 @@ class Detector {
     DevBuf<int> counts_dev_;
     PinnedBuf<LetterboxDesc> descs_pin_;
     PinnedBuf<rmr_preparam> pp_pin_;
-    PinnedBuf<rmr_detection> dets_pin_;
-    PinnedBuf<int> counts_pin_;
+    DevBuf<uint8_t> heads_dev_;      // [B][kHeadRows] rows + B counts, gathered for one contiguous D2H copy
+    PinnedBuf<uint8_t> heads_pin_;
 };
 
 class RobotDetector {
