@@ -12,8 +12,12 @@
 //     column o are plane0[o], plane1[o], plane0[o + 1], so the 16 lanes of a fragment read
 //     consecutive 96-byte pixels -- the conflict-free pattern of conv_ws -- instead of every other
 //     one.  Columns / rows outside the image arrive as zeros from the buffer bounds check;
-//   * results are packed to f16 in registers and stored at the start of the NEXT step, so the
-//     vmcnt(0) that admits a step's input rows never waits on a store just issued.
+//   * results are packed to f16 in registers and stored during the NEXT step.  Neither the 16 row DMAs nor the 15
+//     stores of a step are issued in a block any more (a vector-memory instruction costs its wave 60-180 issue
+//     cycles, and with one wave per SIMD nothing else runs meanwhile): the DMAs ride behind the MFMAs of K-steps
+//     0..3, the stores behind those of K-steps 4..13, bounds-checked buffer stores that are always issued, so the
+//     wait that admits a step's rows is a COUNTED one -- the 15 stores issued after those DMAs may still be in
+//     flight (loads and stores share vmcnt and retire in order).
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -26,6 +30,7 @@ namespace rmr {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -104,9 +109,9 @@ void conv_ws_s2_kernel(const ConvArgs a, const int strip_rows) {
         gbad[j] = ok ? 0u : 0xffffffffu;
     }
     const unsigned row_bytes = (unsigned)(a.W * a.in_cs * 2);
-    auto issue_row = [&](int ry) {
+    auto issue_row = [&](int ry, bool live = true) {
         const int iy = iy_base + ry;
-        const unsigned dead = (iy >= 0 && iy < a.H) ? 0u : 0xffffffffu;
+        const unsigned dead = (live && iy >= 0 && iy < a.H) ? 0u : 0xffffffffu;
         const unsigned rowoff = (unsigned)(img * a.H + iy) * row_bytes;
         const unsigned slot = lds0 + (unsigned)(ry % S2_SLOTS) * S2_SLOT;
 #pragma unroll
@@ -122,15 +127,18 @@ void conv_ws_s2_kernel(const ConvArgs a, const int strip_rows) {
     for (int j = 0; j < 3; ++j) bias[j] = *(const float4*)(a.bias + nh * 48 + j * 16 + cq);
 
     const unsigned lane_off = (unsigned)(frow * S2_PIX + (kg & 1) * 16);
-    uint2 outv[5][3];
+    u32x2 outv[5][3];
     long m_row = 0;
-    auto store_out = [&]() {
+    // f16 results leave through a bounds-checked resource: a cell of the step "before the first one" is stored at an
+    // out-of-range offset (dropped), so the store count per step is a constant
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0xfffffff0u, 0x00020000);
+    unsigned out_row = 0xffffffffu;   // byte offset of (m_row of the PREVIOUS step, this lane's first channel); all ones: none
+    const unsigned out_lane = (unsigned)(px * a.out_cs + a.out_co + nh * 48 + cq) * 2u;
+    auto store_cell = [&](int c) {   // c: compile-time at every call site
         if (OUT32) return;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                *(uint2*)((_Float16*)a.out + (m_row + i * 16 + px) * a.out_cs + a.out_co + nh * 48 + j * 16 + cq) = outv[i][j];
+        const int i = c / 3, j = c % 3;
+        const unsigned off = out_row == 0xffffffffu ? 0xffffffffu : out_row + out_lane + (unsigned)(i * 16 * a.out_cs + j * 16) * 2u;
+        __builtin_amdgcn_raw_buffer_store_b64(outv[i][j], out_rsrc, off, 0, 0);
     };
 
     unsigned vb[3];
@@ -151,13 +159,15 @@ void conv_ws_s2_kernel(const ConvArgs a, const int strip_rows) {
     };
 
     for (int s = 0; s < steps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's rows (issued a step ago) and older stores
+        // this step's rows were issued during the previous step, BEFORE that step's 15 stores (none in step 0, none
+        // with an f32 output): everything older than those stores has landed
+        if (OUT32 || s <= 1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // ... for every wave; step s - 1 is fully consumed
-        if (s + 1 < steps) {
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) issue_row(4 * s + 5 + q);  // the four new rows of step s + 1
-        }
-        if (s > 0) store_out();
+        const bool more = s + 1 < steps;
+        out_row = s > 0 ? (unsigned)(m_row * a.out_cs) * 2u : 0xffffffffu;
         const int y = y_base + 2 * s + r;
         m_row = ((long)img * a.Ho + y) * S2_WO + x0;
 
@@ -177,10 +187,23 @@ void conv_ws_s2_kernel(const ConvArgs a, const int strip_rows) {
             if (ks + 1 < S2_KSTEPS) read_frags(ks + 1, xf[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int c = 0; c < 8; ++c)
+                acc[c / 3][c % 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][c % 3], xf[ks & 1][c / 3], acc[c / 3][c % 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the step's vector-memory work, one piece behind the MFMAs of every K-step: the four rows of step s + 1
+            // (out of range behind the strip's last step: the counts stay constant), then the 15 cells of step s - 1
+            if (ks < 4) {
+                issue_row(4 * s + 5 + ks, more);
+            } else if (ks < 9) {
+                store_cell(2 * (ks - 4));
+                store_cell(2 * (ks - 4) + 1);
+            } else {
+                store_cell(10 + (ks - 9));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
+            for (int c = 8; c < 15; ++c)
+                acc[c / 3][c % 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][c % 3], xf[ks & 1][c / 3], acc[c / 3][c % 3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -200,7 +223,7 @@ void conv_ws_s2_kernel(const ConvArgs a, const int strip_rows) {
                     continue;
                 }
                 union {
-                    uint2 u;
+                    u32x2 u;
                     _Float16 h[4];
                 } o;
 #pragma unroll
@@ -209,7 +232,9 @@ void conv_ws_s2_kernel(const ConvArgs a, const int strip_rows) {
             }
         }
     }
-    store_out();
+    out_row = (unsigned)(m_row * a.out_cs) * 2u;   // the strip's last step
+#pragma unroll
+    for (int c = 0; c < 15; ++c) store_cell(c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -233,6 +258,7 @@ void launch_conv_ws_s2(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int varia
     if (!conv_ws_s2_supported(a, variant)) fail(RMR_ERR_LOGIC, "conv_ws_s2: layer not supported by variant %d", variant);
     if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4) fail(RMR_ERR_LOGIC, "conv_ws_s2: misaligned view");
     if (a.in_bytes > 0xf0000000ull) fail(RMR_ERR_LOGIC, "conv_ws_s2: input view larger than 3.75 GiB");
+    if (!a.out32 && (double)a.M * a.out_cs * 2 >= 4.0e9) fail(RMR_ERR_LOGIC, "conv_ws_s2: output view of 4 GB or more (32-bit store offsets)");
     using Kern = void (*)(const ConvArgs, int);
     static const Kern kernels[4] = {conv_ws_s2_kernel<false, false>, conv_ws_s2_kernel<false, true>,
                                     conv_ws_s2_kernel<true, false>, conv_ws_s2_kernel<true, true>};
