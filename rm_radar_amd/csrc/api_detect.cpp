@@ -435,6 +435,18 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
                 if (tile - 800 >= conv_t32_num_tiles() || !conv_t32_supported(a, tile - 800))
                     fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: t32 tile %d cannot run this layer", tile - 800);
                 launch_conv_t32(ctx, ctx.stream, a, tile - 800);
+            } else if (tile >= 700 && tile < 800) {
+                if (tile - 700 >= conv_pw_num_variants() || !conv_pw_supported(a, tile - 700))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: pw variant %d cannot run this layer", tile - 700);
+                launch_conv_pw(ctx, ctx.stream, a, tile - 700);
+            } else if (tile >= 600 && tile < 700) {
+                if (tile - 600 >= conv_ws_s2_num_variants() || !conv_ws_s2_supported(a, tile - 600))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: ws_s2 variant %d cannot run this layer", tile - 600);
+                launch_conv_ws_s2(ctx, ctx.stream, a, tile - 600);
+            } else if (tile >= 300 && tile < 400) {
+                if (tile - 300 >= conv_ws_num_variants() || !conv_ws_supported(a, tile - 300))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: ws variant %d cannot run this layer", tile - 300);
+                launch_conv_ws(ctx, ctx.stream, a, tile - 300);
             } else if (tile >= 200 && tile < 300) {
                 if (tile - 200 >= conv_halo_num_tiles() || !conv_halo_supported(a, tile - 200))
                     fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: halo tile %d cannot run this layer", tile - 200);

@@ -145,23 +145,34 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
         q_row[j] = q >= WS_DMA_ROW ? 0xffffffffu : 0u;
         q_dst[j] = (unsigned)(WS_PIX + (q % WS_DMA_ROW) * 1024);
     }
-    auto issue_pair = [&](int ry0) {  // rows ry0, ry0 + 1
+    // a row pair's wave-uniform constants, then one DMA per slot j: the step loop issues the slots one by one behind
+    // its MFMAs, the prologue all at once
+    struct Pair {
+        unsigned live0, live1, rowoff0, slot0, slot1;
+    };
+    const unsigned row_bytes = (unsigned)(WS_W * a.in_cs * 2);
+    auto pair_of = [&](int ry0) {  // rows ry0, ry0 + 1
         const int gy0 = y_base - 1 + ry0;
-        const unsigned live0 = (gy0 >= 0 && gy0 < a.H && ry0 <= strip_rows + 1) ? 0xffffffffu : 0u;
-        const unsigned live1 = (gy0 + 1 >= 0 && gy0 + 1 < a.H && ry0 + 1 <= strip_rows + 1) ? 0xffffffffu : 0u;
-        const unsigned row_bytes = (unsigned)(WS_W * a.in_cs * 2);
-        const unsigned rowoff0 = (unsigned)(img_row0 + gy0) * row_bytes;
-        const unsigned slot0 = lds0 + (unsigned)(ry0 % WS_SLOTS) * WS_ROW;
-        const unsigned slot1 = lds0 + (unsigned)((ry0 + 1) % WS_SLOTS) * WS_ROW;
+        Pair p;
+        p.live0 = (gy0 >= 0 && gy0 < a.H && ry0 <= strip_rows + 1) ? 0xffffffffu : 0u;
+        p.live1 = (gy0 + 1 >= 0 && gy0 + 1 < a.H && ry0 + 1 <= strip_rows + 1) ? 0xffffffffu : 0u;
+        p.rowoff0 = (unsigned)(img_row0 + gy0) * row_bytes;
+        p.slot0 = lds0 + (unsigned)(ry0 % WS_SLOTS) * WS_ROW;
+        p.slot1 = lds0 + (unsigned)((ry0 + 1) % WS_SLOTS) * WS_ROW;
+        return p;
+    };
+    auto issue_slot = [&](const Pair& p, int j) {  // j: compile-time at every call site
+        const unsigned live = q_ok[j] & ((q_row[j] & p.live1) | (~q_row[j] & p.live0));
+        const unsigned rowoff = p.rowoff0 + (q_row[j] & row_bytes);
+        const unsigned off = (goff[j] + rowoff) | ~live;  // dead slots: offset 0xffffffff is out of range
+        const unsigned slot = (q_row[j] & p.slot1) | (~q_row[j] & p.slot0);
+        const unsigned dst = (q_ok[j] & (slot + q_dst[j])) | (~q_ok[j] & scratch);
+        dma16w(in_rsrc, sgpr(dst), off);
+    };
+    auto issue_pair = [&](int ry0) {
+        const Pair p = pair_of(ry0);
 #pragma unroll
-        for (int j = 0; j < WS_NI; ++j) {
-            const unsigned live = q_ok[j] & ((q_row[j] & live1) | (~q_row[j] & live0));
-            const unsigned rowoff = rowoff0 + (q_row[j] & row_bytes);
-            const unsigned off = (goff[j] + rowoff) | ~live;  // dead slots: offset 0xffffffff is out of range
-            const unsigned slot = (q_row[j] & slot1) | (~q_row[j] & slot0);
-            const unsigned dst = (q_ok[j] & (slot + q_dst[j])) | (~q_ok[j] & scratch);
-            dma16w(in_rsrc, sgpr(dst), off);
-        }
+        for (int j = 0; j < WS_NI; ++j) issue_slot(p, j);
     };
     issue_pair(0);
     issue_pair(2);
@@ -189,14 +200,21 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
     const u32x4 res_rsrc = {sgpr((unsigned)(size_t)a.res), sgpr((unsigned)((size_t)a.res >> 32) & 0xffffu),
                             sgpr(0xffffffffu), sgpr(0x00020000u)};
     long m_row = 0;
-    auto drain = [&]() {  // the previous step's results: stage -> global, 16 bytes per lane
+    // the previous step's results leave as 16-byte pieces: read from the stage at the step's start (before the
+    // residual DMAs overwrite it), stored one by one behind the MFMAs through a bounds-checked resource -- a piece
+    // without a pixel, or of the step "before the first", goes to an out-of-range offset, so the count is constant
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0xfffffff0u, 0x00020000);
+    u32x4 dv[WS_NI];
+    unsigned out_row = 0xffffffffu;   // byte offset of the previous step's first pixel; all ones: there is none
+    auto drain_reads = [&]() {
         if (OUT32) return;
-        u32x4 v[WS_NI];
 #pragma unroll
-        for (int t = 0; t < WS_NI; ++t) v[t] = *(const u32x4*)(stage_p + (lane + 64 * t) * 16);
-#pragma unroll
-        for (int t = 0; t < WS_NI; ++t)
-            if (cmask[t]) *(u32x4*)((unsigned char*)a.out + m_row * a.out_cs * 2 + ooff[t]) = v[t];
+        for (int t = 0; t < WS_NI; ++t) dv[t] = *(const u32x4*)(stage_p + (lane + 64 * t) * 16);
+    };
+    auto drain_store = [&](int t) {  // t: compile-time at every call site
+        if (OUT32) return;
+        const unsigned off = (out_row == 0xffffffffu ? 0xffffffffu : out_row + ooff[t]) | ~cmask[t];
+        __builtin_amdgcn_raw_buffer_store_b128(dv[t], out_rsrc, off, 0, 0);
     };
 
     float4 bias[NT];
@@ -219,22 +237,39 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
         for (int i = 0; i < 5; ++i) xf[i] = *(const __attribute__((address_space(3))) half8*)(p + i * 16 * WS_PIX);
     };
 
+    // Vector-memory instructions of a step, in issue order: the residual DMAs (needed by this step's epilogue), the
+    // row-pair DMAs (needed two steps on), the stores of the previous step's results.  They are NOT issued in a block
+    // at the step's start (a vector-memory instruction costs its wave 60-180 issue cycles and the MFMA pipe runs dry
+    // meanwhile) but NVM_PER at a time behind the MFMAs of the K steps; the waits count what may still be in flight
+    // (loads and stores share vmcnt and retire in order).
+    constexpr int N_RES = RES ? WS_NI : 0;
+    constexpr int N_ST = OUT32 ? 0 : WS_NI;
+    constexpr int NVM = N_RES + WS_NI + N_ST;
+    constexpr int NVM_PER = (NVM + WS_KSTEPS - 1) / WS_KSTEPS;
+    static_assert(NVM <= 63, "vmcnt is 6 bits");
     for (int s = 0; s < steps; ++s) {
-        // Every wave's DMA of the row pair issued two steps ago has landed once each wave has at
-        // most its newest WS_NI loads in flight (loads retire in order; the stores issued before
-        // them only make the wait more conservative) and all waves have met at the barrier.
-        wait_vmw<WS_NI>();
+        // The rows of this step were issued two steps ago (or by the prologue): everything older than the previous
+        // step's own instructions has landed.  (Step 0: the prologue's third pair may still be in flight.)
+        if (s == 0)
+            wait_vmw<WS_NI>();
+        else
+            wait_vmw<NVM>();
         __builtin_amdgcn_s_barrier();    // also: step s - 1 is fully consumed by every wave
-        if (s > 0) drain();
-        issue_pair(2 * s + 6);           // rows of step s + 2 (slots last read in step s - 1)
+        drain_reads();
+        out_row = s > 0 ? (unsigned)(m_row * a.out_cs * 2) : 0xffffffffu;
+        const Pair pair = pair_of(2 * s + 6);   // rows of step s + 2 (slots last read in step s - 1)
         const int y = y_base + 2 * s + r;
         m_row = ((long)img_row0 + y) * WS_W + xh * 80;
-        if (RES) {  // this wave's residual pixels -> its stage (after the drain's reads: same wave, LDS ops in order)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned rbase = (unsigned)(m_row * a.res_cs * 2);
-#pragma unroll
-            for (int t = 0; t < WS_NI; ++t) dma16w(res_rsrc, sgpr(stage + t * 1024), (roff[t] + rbase) | ~cmask[t]);
-        }
+        const unsigned rbase = RES ? (unsigned)(m_row * a.res_cs * 2) : 0u;
+        if (RES) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is read before the residual lands in it
+        const auto vm_op = [&](int v) {  // v: compile-time at every call site
+            if (v < N_RES)  // this wave's residual pixels -> its stage
+                dma16w(res_rsrc, sgpr(stage + v * 1024), (roff[v < N_RES ? v : 0] + rbase) | ~cmask[v < N_RES ? v : 0]);
+            else if (v < N_RES + WS_NI)
+                issue_slot(pair, v - N_RES);
+            else if (v < NVM)
+                drain_store(v - N_RES - WS_NI);
+        };
 
         // LDS address of this lane's pixel column in the three input rows of its output row
 #pragma unroll
@@ -252,16 +287,22 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
         for (int ks = 0; ks < WS_KSTEPS; ++ks) {
             if (ks + 1 < WS_KSTEPS) read_frags(ks + 1, xf[(ks + 1) & 1]);  // next K step's reads ride under these MFMAs
             __builtin_amdgcn_sched_barrier(0);
+            constexpr int HALF = (5 * NT + 1) / 2;
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int c = 0; c < HALF; ++c)
+                acc[c / NT][c % NT] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][c % NT], xf[ks & 1][c / NT], acc[c / NT][c % NT], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
+            for (int v = ks * NVM_PER; v < (ks + 1) * NVM_PER; ++v) vm_op(v);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = HALF; c < 5 * NT; ++c)
+                acc[c / NT][c % NT] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][c % NT], xf[ks & 1][c / NT], acc[c / NT][c % NT], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- epilogue of the step: bias, SiLU, residual -> packed f16 into the stage --------------
-        if (RES) wait_vmw<0>();  // own residual DMA (and, being older, everything else) has landed
+        if (RES) wait_vmw<WS_NI + N_ST>();  // own residual DMAs (and everything older) have landed; the pair DMAs and stores behind them need not
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
 #pragma unroll
@@ -297,7 +338,11 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
             }
         }
     }
-    drain();
+    // the strip's last step
+    drain_reads();
+    out_row = (unsigned)(m_row * a.out_cs * 2);
+#pragma unroll
+    for (int t = 0; t < WS_NI; ++t) drain_store(t);
     wait_vmw<0>();
 }
 
@@ -324,6 +369,7 @@ void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
     if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8 || a.res_cs % 8 || a.res_co % 8)
         fail(RMR_ERR_LOGIC, "conv_ws: misaligned view");
     if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull) fail(RMR_ERR_LOGIC, "conv_ws: input view size not set or larger than 3.75 GiB");
+    if (!a.out32 && (double)a.M * a.out_cs * 2 >= 4.0e9) fail(RMR_ERR_LOGIC, "conv_ws: output view of 4 GB or more (32-bit store offsets)");
     using Kern = void (*)(const ConvArgs, int);
 #define WS_KERNELS(NJ)                                                                                   \
     {conv_ws_kernel<false, false, false, NJ>, conv_ws_kernel<false, false, true, NJ>,                    \
