@@ -151,17 +151,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
         }
     }
     int i_blk = 0;  // row block of the next stage to issue
-    auto issue = [&](int slot, const int pos) {  // pos: compile-time at every call site
+    // a stage's DMA instructions: wave-uniform set-up once (issue_begin), then one instruction per call (issue_one) so
+    // that the walk can place them behind its MFMAs; issue() = all of them at once (the prologue)
+    unsigned is_base = 0, is_dead = 0;
+    int is_m0 = 0;
+    auto issue_begin = [&]() {
         const bool live = i_blk < nb;  // wave-uniform; past the end: no-ops keep the counts constant
-        const int m0 = (w + i_blk * G) * BM;
-        const unsigned base = (unsigned)(m0 * a.in_cs) * 2u;
-        const unsigned dead = live ? 0u : 0xffffffffu;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const unsigned off = (d_off[pos][j] + base) | dead | (m0 + d_row[j] < a.M ? 0u : 0xffffffffu);
-            dma16p(in_rsrc, sgpr(lds0 + slot * STAGE_BYTES + d_dst[j]), off);
-        }
+        is_m0 = (w + i_blk * G) * BM;
+        is_base = (unsigned)(is_m0 * a.in_cs) * 2u;
+        is_dead = live ? 0u : 0xffffffffu;
+    };
+    auto issue_one = [&](int slot, const int pos, const int j) {  // pos, j: compile-time at every call site
+        const unsigned off = (d_off[pos][j] + is_base) | is_dead | (is_m0 + d_row[j] < a.M ? 0u : 0xffffffffu);
+        dma16p(in_rsrc, sgpr(lds0 + slot * STAGE_BYTES + d_dst[j]), off);
+    };
+    auto issue_end = [&](const int pos) {
         if (pos == E - 1) ++i_blk;
+    };
+    auto issue = [&](int slot, const int pos) {
+        issue_begin();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) issue_one(slot, pos, j);
+        issue_end(pos);
     };
 
     // prologue: STAGES - 1 stages in flight.  In steady state the stores of epilogue u sit right after
@@ -232,11 +243,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
                                      : "memory");
                 }
             }
-            {
-                int nxt = slot + STAGES - 1;
-                if (nxt >= STAGES) nxt -= STAGES;
-                issue(nxt, (p + STAGES - 1) % E);
-            }
+            // the next stage's DMA instructions ride behind the MFMAs of this stage's K steps, NI_PER at a time: a
+            // vector-memory instruction costs its wave 60-180 issue cycles, and the variants with one wave per SIMD
+            // have nobody else to feed the matrix pipe meanwhile (the order of DMAs, addend loads and stores -- what
+            // the counted waits rely on -- is unchanged)
+            int nxt = slot + STAGES - 1;
+            if (nxt >= STAGES) nxt -= STAGES;
+            issue_begin();
+            constexpr int NI_PER = (NI + PW_SPS - 1) / PW_SPS;
+            constexpr int NMF = MREP * PW_NREP, HALF = (NMF + 1) / 2;
             const unsigned char* const sp = smem + slot * STAGE_BYTES + a_base;
 #pragma unroll
             for (int ss = 0; ss < PW_SPS; ++ss) {
@@ -244,11 +259,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_pw_kernel(const ConvArgs a, 
 #pragma unroll
                 for (int i = 0; i < MREP; ++i) xf[i] = *(const half8*)(sp + ss * SSB + i * 16 * 64);
 #pragma unroll
-                for (int i = 0; i < MREP; ++i)
+                for (int c = 0; c < HALF; ++c)
+                    acc[c / PW_NREP][c % PW_NREP] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[p * PW_SPS + ss][c % PW_NREP], xf[c / PW_NREP], acc[c / PW_NREP][c % PW_NREP], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < PW_NREP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[p * PW_SPS + ss][j], xf[i], acc[i][j], 0, 0, 0);
+                for (int j = ss * NI_PER; j < (ss + 1) * NI_PER && j < NI; ++j) issue_one(nxt, (p + STAGES - 1) % E, j);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = HALF; c < NMF; ++c)
+                    acc[c / PW_NREP][c % PW_NREP] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[p * PW_SPS + ss][c % PW_NREP], xf[c / PW_NREP], acc[c / PW_NREP][c % PW_NREP], 0, 0, 0);
             }
+            issue_end((p + STAGES - 1) % E);
             if (++slot == STAGES) slot = 0;
             if (p == E - 1) {
                 // ---- epilogue of the row block: bias, SiLU, store 4 consecutive channels per lane ----

@@ -72,6 +72,9 @@ int main() {
     loc.search(robots);
     if (!robots[0].isLocated()) return std::puts("FAIL search"), 1;
     loc.update(CloudView{});  // null cloud: message + early return (locate.cpp:160-165)
+    // throughput form: update + cluster of a batch of frames (here one, the null cloud: nothing in the foreground)
+    loc.updateClusterBatch({CloudView{}});
+    if (rmr_locator_num_clusters(loc.handle()) != 0) return std::puts("FAIL updateClusterBatch"), 1;
     std::printf("api_smoke ok: located at [%f %f %f] m\n", robots[0].location()->x, robots[0].location()->y,
                 robots[0].location()->z);
     return 0;
