@@ -345,6 +345,48 @@ def test_update_cluster_batch_equals_per_frame_calls(rmr, max_fg):
     loc = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, eye, max_frames=2)
     with pytest.raises(rmr.InvalidArgument):
         loc.update_cluster_batch([first, first, first])   # more frames than max_frames
+    loc.close()
+
+
+def test_update_cluster_batch_reports_an_overflow_in_any_frame(rmr):
+    # the foreground of ONE frame inside a batch exceeds max_foreground: the batched search reports it (the per-frame
+    # calls would only see the flag of the last cluster())
+    import ctypes as C
+    from rm_radar_amd import _lib
+    size, nf, cap = (640, 640), 4, 2
+    eye = np.eye(4, dtype=np.float32)
+    rng = np.random.default_rng(5)
+    first = scenes.make_cloud(rng, 30000, scenes.K640, scenes.SAMPLE_L2C, size)
+    rect = (100, 300, 300, 200)   # queue_size 1 below: a frame's foreground is its own points only
+    clouds = [scenes.make_cloud(rng, 20000, scenes.K640, scenes.SAMPLE_L2C, size, [(rect, 2000.0, 3000 if f == 1 else 150)]) for f in range(nf)]
+    # foreground sizes frame by frame, to put max_foreground between the dense frame's and the others'
+    probe = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, eye, queue_size=1)
+    probe.update(first)
+    n_fg = []
+    for c in clouds:
+        probe.update(c)
+        probe.cluster()
+        n_fg.append(len(probe.foreground()[1]))
+    probe.close()
+    others = max(n for f, n in enumerate(n_fg) if f != 1)
+    assert n_fg[1] > others + 64, n_fg
+    max_fg = (n_fg[1] + others) // 2
+    loc = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, eye, max_frames=nf, max_foreground=max_fg, queue_size=1)
+    loc.update(first)
+    loc.update_cluster_batch(clouds)
+    arr = (_lib.Robot * (nf * cap))()
+    for f in range(nf):
+        arr[f * cap].rect[:] = [float(v) for v in rect]
+    with pytest.raises(rmr.CapacityError):
+        loc.search_batch_raw(arr, np.ones(nf, np.int32), cap)
+    loc.close()
+    # the same stream without the dense frame: nothing overflows
+    clouds[1] = clouds[0]
+    loc2 = rmr.Locator(size[0], size[1], scenes.K640, scenes.SAMPLE_L2C, eye, max_frames=nf, max_foreground=max_fg, queue_size=1)
+    loc2.update(first)
+    loc2.update_cluster_batch(clouds)
+    loc2.search_batch_raw(arr, np.ones(nf, np.int32), cap)
+    loc2.close()
 
 
 def test_dense_foreground_beyond_one_workgroup(rmr, oracle):
