@@ -64,7 +64,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -89,12 +89,43 @@ def parse():
                     help="fp8 = BASELINE configs[4]: e4m3 weights and activations in the 3x3 layers of backbone and neck")
     ap.add_argument("--config", type=int, default=2, help="BASELINE configs index: 2 = 640x640 + 30k points; 3 = one 1920x1080 "
                     "stream + 100k-point clouds per GPU")
-    args = ap.parse_args()
+    ap.add_argument("--stub-step", action="store_true",
+                    help="TEST HOOK (tests/test_bench_launcher.py): the launcher, process group (gloo), C-ABI communicator (FILE "
+                         "transport), barriers, max-over-ranks clock and JSON assembly run for real on CPU; the GPU step is replaced "
+                         "by a stand-in that only fabricates robot records.  The line says \"stub\": true and measures nothing")
+    args = ap.parse_args(argv)
     if args.config == 3:
         args.size, args.height, args.points = 1920, 1080, 100000
     if args.config == 4:   # fp8-MFMA weights, batch = 256
         args.dtype, args.batch = "fp8", 256
     return args
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks of this same script, one per GPU, under
+    torch.distributed.run -- the command form the contract gives for N > 1 -- and hand back its exit code.  A box
+    with fewer than N GPUs is an error, never a silent one-rank run."""
+    import subprocess
+    if not args.stub_step:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node has {have}; "
+                             "refusing to run fewer ranks than asked for\n")
+            return 3
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def frame_size(args):
@@ -168,28 +199,151 @@ def cpu_baseline(args, packs, images, clouds, rects):
                       f"PyTorch-CPU fp32, C oracle pre/post/locate), {dt:.1f} s"}
 
 
-def main():
-    args = parse()
+class Ranks:
+    """What every rank of a run shares, GPU or stub: the process group the launcher's environment describes, the
+    C-ABI communicator of the robot-record exchange (include/rmr.h rmr_comm_*: RCCL on GPUs, the FILE transport
+    on CPU), the barrier and the max-over-ranks clock of the contract."""
+
+    def __init__(self, args, backend, transport, device=None):
+        import torch
+        import torch.distributed as dist
+        from rm_radar_amd import dist as rd
+        self.torch, self.dist, self.rd = torch, dist, rd
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.gpu = backend == "nccl"
+        # under torch.distributed.run (RANK set) the process group is always created, also for one
+        # rank, so the RCCL path is exercised by every launcher-driven run
+        self.use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {"device_id": torch.device("cuda", self.local)} if self.gpu else {}
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+        self.dev = torch.device("cuda", self.local) if self.gpu else torch.device("cpu")
+        self.comm, self.ranks_seen = None, [0]
+        self.gather_via = "none (one rank, no process group)"
+        if self.use_dist:
+            self.gather_via = f"torch.distributed all_gather_into_tensor ({'RCCL' if self.gpu else 'gloo'})"
+            self.ranks_seen = self._probe_torch()
+            if args.gather == "abi":
+                # the 128-byte id travels over the torch.distributed group that exists anyway for the barrier and
+                # the clock.  A failure to set the communicator up falls back to torch.distributed and says so.
+                try:
+                    ids = [rd.Comm.unique_id(transport) if self.rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    self.comm = rd.Comm(transport, self.rank, self.world, ids[0], device=self.local)
+                    probe = self.comm.all_gather_records(np.full((1, 1, rd.RECORD_WORDS), self.rank + 1, np.int32))
+                    seen = [int(probe[r, 0, 0, 0]) - 1 for r in range(probe.shape[0])]
+                    assert seen == list(range(self.world)), seen
+                    self.ranks_seen = seen
+                    self.gather_via = ("rmr_comm_all_gather_records (C-ABI, " +
+                                       ("RCCL ncclAllGather" if transport == "rccl" else "FILE transport") + ")")
+                except Exception as e:  # noqa: BLE001
+                    self.comm = None
+                    self.gather_via += f" [C-ABI communicator unavailable: {type(e).__name__}: {e}]"
+
+    def _probe_torch(self):
+        t = self.torch.full((1,), self.rank, dtype=self.torch.int32, device=self.dev)
+        out = self.torch.empty((self.world,), dtype=self.torch.int32, device=self.dev)
+        self.dist.all_gather_into_tensor(out, t)
+        return [int(v) for v in out.cpu()]
+
+    def gather(self, block):
+        """block: this rank's int32 [frames, cap, 12] records (numpy) -> [world, frames, cap, 12] (torch, CPU or device)."""
+        torch = self.torch
+        if self.comm is not None:
+            return torch.from_numpy(self.comm.all_gather_records(block))
+        if self.use_dist:
+            return self.rd.all_gather_records(torch.from_numpy(block).to(self.dev), force=True)
+        return torch.from_numpy(block)[None]
+
+    def sync(self):
+        if self.gpu:
+            self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+            if self.gpu:
+                self.torch.cuda.synchronize()
+
+    def timed(self, step, n):
+        """EXACTLY n steps between two barrier + synchronize pairs; returns (max over ranks, every rank's own time)."""
+        self.sync()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(n):
+            last = step()
+        self.sync()
+        dt = time.perf_counter() - t0
+        per_rank = [dt]
+        if self.use_dist:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+            out = self.torch.empty((self.world,), dtype=self.torch.float64, device=self.dev)
+            self.dist.all_gather_into_tensor(out, t)
+            per_rank = [float(v) for v in out.cpu()]
+        return max(per_rank), per_rank, last
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        if self.use_dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def main_stub(args):
+    """--stub-step: everything around the step for real (launcher -> ranks -> gloo group -> FILE-transport communicator ->
+    barriers -> max-over-ranks clock -> one JSON line from rank 0), the step itself a stand-in.  No GPU, no librmr compute."""
+    from rm_radar_amd import dist as rd
+    R = Ranks(args, "gloo", "file")
+    B, cap = args.batch, max(args.crops, 1)
+    rng = np.random.default_rng(R.rank)
+
+    def step():
+        time.sleep(0.002 * (1 + R.rank))            # ranks deliberately unequal: the clock must be the slowest rank's
+        block = np.zeros((B, cap, rd.RECORD_WORDS), np.int32)
+        block[:, :, 9] = 4                          # valid slots
+        block[:, :, 10] = R.rank                    # stream id = rank (stream s lives on rank s % world)
+        block[:, :, 11] = np.arange(B)[:, None]
+        block[:, :, 0] = rng.integers(0, 640, (B, cap))
+        return R.gather(block)
+
+    for _ in range(args.warmup):
+        step()
+    dt, per_rank, block = R.timed(step, args.steps)
+    streams = sorted({int(v) for v in block.reshape(-1, rd.RECORD_WORDS)[:, 10]})
+    if R.rank == 0:
+        print(json.dumps({
+            "stub": True, "metric": "NOT A MEASUREMENT: bench.py --stub-step (launcher / harness test)", "value": B * args.steps * R.world / dt,
+            "unit": "stub frames/s", "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
+            "config": {"workload": "stub", "frames_per_step_per_gpu": B}, "ranks_seen": R.ranks_seen, "gather": R.gather_via,
+            "per_rank_frames_per_s": [round(B * args.steps / t, 2) for t in per_rank],
+            "gathered_shape": list(block.shape), "streams_in_gathered_list": streams}))
+    R.close()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch as "
+                         f"`python bench.py --gpus {args.gpus}` or under torch.distributed.run --nproc-per-node {args.gpus}\n")
+        sys.exit(3)
+    if args.stub_step:
+        return main_stub(args)
     import torch
-    import torch.distributed as dist
 
     import rm_radar_amd as rmr
     import scenes
     from rm_radar_amd import dist as rd
     from rm_radar_amd import weights as W
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # under torch.distributed.run (RANK set) the process group is always created, also for one
-    # rank, so the RCCL path is exercised by every launcher-driven run
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+    R = Ranks(args, "nccl", "rccl")
+    world, rank, local, use_dist, dev = R.world, R.rank, R.local, R.use_dist, R.dev
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
     pack_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rmr_packs")
     os.makedirs(pack_dir, exist_ok=True)
@@ -227,47 +381,19 @@ def main():
     frames = rmr.FrameBatch(img_list, cloud_list)
     forced = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(B, -1, 4))
 
-    # The exchange of the path: by default through the C-ABI a C++ host would use (include/rmr.h, rmr_comm_*:
-    # ncclAllGather on this rank's GPU); the 128-byte id travels over the torch.distributed group that exists
-    # anyway for the barrier and the max-over-ranks clock.  A failure to set it up falls back to torch.distributed.
-    comm, gather_via = None, "none (one rank, no process group)"
-    if use_dist:
-        gather_via = "torch.distributed all_gather_into_tensor (RCCL)"
-        if args.gather == "abi":
-            try:
-                ids = [rd.Comm.unique_id("rccl") if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                comm = rd.Comm("rccl", rank, world, ids[0], device=local)
-                probe = comm.all_gather_records(np.full((1, 1, rd.RECORD_WORDS), rank + 1, np.int32))
-                assert probe.shape[0] == world and all(int(probe[r, 0, 0, 0]) == r + 1 for r in range(world))
-                gather_via = "rmr_comm_all_gather_records (C-ABI, RCCL ncclAllGather)"
-            except Exception as e:  # noqa: BLE001
-                comm = None
-                gather_via += f" [C-ABI communicator unavailable: {type(e).__name__}: {e}]"
-
     def step():
         # one native call in the reference's order (sample_radar.h:106-127): update + cluster of
         # the 64 frames on a helper thread while detect runs, join, then one batched search
         t0 = time.perf_counter()
         robots, counts = rmr.run_batch(rdet, loc, frames, None, forced)
         t3 = time.perf_counter()
-        block = rd.pack_records(robots, counts, cap, rank, cap)
-        if comm is not None:
-            block = torch.from_numpy(comm.all_gather_records(block))
-        elif use_dist:
-            block = rd.all_gather_records(torch.from_numpy(block).to(dev), force=True)
-        else:
-            block = torch.from_numpy(block)
+        block = R.gather(rd.pack_records(robots, counts, cap, rank, cap))
         t4 = time.perf_counter()
         phases["detect_locate_search"] += t3 - t0
         phases["pack_gather"] += t4 - t3
         return block, counts
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+    sync_all = R.sync
 
     # untimed: the first call autotunes every layer for the two batch sizes (the analogue of the
     # reference's TensorRT engine build, detector.cpp:177-243) -- kept apart from the W warm-up steps
@@ -279,30 +405,14 @@ def main():
     for k in phases:
         phases[k] = 0.0
     # ---- 2. headline: exactly K steps, nothing profiled -------------------------------------------------
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        block, counts = step()
-    sync_all()
-    dt = time.perf_counter() - t0
+    dt, per_rank_dt, (block, counts) = R.timed(step, args.steps)
     headline_phases = {k: v for k, v in phases.items()}
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
 
     # ---- 3. steady state: the same loop until --seconds are on the clock (all ranks run the same count)
     steady = None
     if args.seconds > dt:
         extra = max(1, int((args.seconds - dt) / (dt / args.steps) + 0.5))
-        t0 = time.perf_counter()
-        for _ in range(extra):
-            step()
-        sync_all()
-        dt2 = time.perf_counter() - t0
-        t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt2 = float(t.item())
+        dt2, _, _ = R.timed(step, extra)
         steady = {"steps": args.steps + extra, "seconds": round(dt + dt2, 3),
                   "value": round(B * (args.steps + extra) * world / (dt + dt2), 2), "unit": "frames/s"}
 
@@ -436,7 +546,9 @@ def main():
             "value_incl_h2d": None if h2d_ms is None else round(B * world / (dt / args.steps + h2d_ms * 1e-3), 2),
             "end_to_end_tflops": round(flops_frame * frames / dt / 1e12, 2),
             "host_phase_ms_per_step": {k: round(v / args.steps * 1e3, 2) for k, v in headline_phases.items()},
-            "gather": gather_via,
+            "gather": R.gather_via,
+            "ranks_seen": R.ranks_seen,
+            "per_rank_frames_per_s": [round(B * args.steps / t, 2) for t in per_rank_dt],
             "located_last_step": n_located,
         }
 
@@ -467,9 +579,7 @@ def main():
         if "cpu_baseline" not in result:
             result["cpu_baseline"] = None
         print(json.dumps(result))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@
 //                       communicator, so hosts that never go multi-GPU do not load it.
 //   RMR_TRANSPORT_FILE  the same exchange through a shared directory (the id is its path): for hosts and CI
 //                       boxes without GPUs, and for testing a C++ caller with several processes on one box.
+#include <dirent.h>
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -37,6 +38,7 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;   // the dlopen / dlsym message, captured where it happened (dlerror() clears itself when read)
 };
 
 Rccl& rccl() {
@@ -46,6 +48,8 @@ Rccl& rccl() {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            const char* e = dlerror();
+            r.why += std::string(r.why.empty() ? "" : "; ") + (e ? e : name);
         }
         if (!r.lib) return;
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
@@ -53,9 +57,11 @@ Rccl& rccl() {
         r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
+            r.why = "ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy missing from the library";
     });
     if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
-        fail(RMR_ERR_DEVICE, "librccl.so cannot be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+        fail(RMR_ERR_DEVICE, "librccl.so cannot be loaded: %s", r.why.c_str());
     return r;
 }
 
@@ -71,12 +77,50 @@ struct rmr_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     DevBuf<unsigned char> send, recv;
-    // FILE
+    // FILE: every file of a communicator carries its EPOCH (the number of communicators this rank has created on the
+    // directory before, a collective count: all ranks create communicators in the same order), so a second
+    // communicator on a directory -- a rank restarted after a crash, a caller-supplied path -- can never read a
+    // record file an earlier one left behind
     std::string dir;
-    long long seq = 0;
+    long long epoch = 0, seq = 0;
+    bool joined = false;   // the session marker is written: the leave protocol applies
+    std::string file(const char* kind, long long s, int r) const {
+        return dir + "/e" + std::to_string(epoch) + "." + kind + (s >= 0 ? std::to_string(s) : std::string()) + "." + std::to_string(r);
+    }
+    bool wait_all(const char* kind, double seconds) const {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < world; ++r) {
+            struct stat st;
+            while (stat(file(kind, -1, r).c_str(), &st) != 0) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+                std::this_thread::sleep_for(std::chrono::microseconds(500));
+            }
+        }
+        return true;
+    }
+    static void touch(const std::string& path) { std::ofstream f(path, std::ios::binary | std::ios::trunc); }
+    // Leaving: a peer may still be reading this rank's last record files, so a rank first says it will read no more
+    // ("done"), removes its own files once every rank has said so, and says "gone"; rank 0 waits for that and sweeps
+    // the markers (and the directory, when rmr_comm_unique_id made it).  A peer that never arrives (crashed) costs a
+    // bounded wait and leaves its epoch's files behind -- which the next communicator's epoch makes harmless.
+    void leave_dir() {
+        if (!joined) return;
+        touch(file("done", -1, rank));
+        const bool all = wait_all("done", 5.0);
+        if (all) {
+            for (long long s = std::max(0LL, seq - 2); s < seq; ++s) std::remove(file("", s, rank).c_str());
+        }
+        touch(file("gone", -1, rank));
+        if (rank != 0 || !all || !wait_all("gone", 5.0)) return;
+        for (int r = 0; r < world; ++r)
+            for (const char* kind : {"done", "gone", "session"}) std::remove(file(kind, -1, r).c_str());
+        const size_t slash = dir.find_last_of('/');
+        if (dir.compare(slash == std::string::npos ? 0 : slash + 1, 9, "rmr_comm_") == 0) (void)rmdir(dir.c_str());
+    }
     ~rmr_comm() {
         if (comm) (void)rccl().CommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
+        if (transport == RMR_TRANSPORT_FILE) leave_dir();
     }
 };
 
@@ -134,6 +178,20 @@ rmr_status rmr_comm_create(int transport, int device, int rank, int world, const
             struct stat st;
             if (c->dir.empty() || stat(c->dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: '%s' is not a directory", c->dir.c_str());
+            // epoch = 1 + the highest session marker this rank has left on the directory
+            const std::string tail = ".session." + std::to_string(rank);
+            long long last = -1;
+            if (DIR* d = opendir(c->dir.c_str())) {
+                while (const dirent* e = readdir(d)) {
+                    const std::string n = e->d_name;
+                    if (n.size() > tail.size() + 1 && n[0] == 'e' && n.compare(n.size() - tail.size(), tail.size(), tail) == 0)
+                        last = std::max(last, std::atoll(n.c_str() + 1));
+                }
+                closedir(d);
+            }
+            c->epoch = last + 1;
+            rmr_comm::touch(c->file("session", -1, rank));
+            c->joined = true;
         } else {
             fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: unknown transport %d", transport);
         }
@@ -163,10 +221,10 @@ rmr_status rmr_comm_all_gather_records(rmr_comm* c, const rmr_robot_record* mine
             RMR_HIP(hipStreamSynchronize(c->stream));
             return;
         }
-        // FILE: publish <seq>.<rank> (written under another name, then renamed: readers never see a partial file),
+        // FILE: publish e<epoch>.<seq>.<rank> (written under another name, then renamed: readers never see a partial file),
         // collect everybody's, retire the files of two rounds ago (every rank has read them by then)
         const long long seq = c->seq++;
-        const auto name = [&](long long s, int r) { return c->dir + "/" + std::to_string(s) + "." + std::to_string(r); };
+        const auto name = [&](long long s, int r) { return c->file("", s, r); };
         {
             const std::string tmp = name(seq, c->rank) + ".tmp";
             std::ofstream f(tmp, std::ios::binary | std::ios::trunc);

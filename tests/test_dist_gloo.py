@@ -157,3 +157,55 @@ def test_python_comm_mirror_matches_numpy_packing(tmp_path):
     assert np.array_equal(comm.all_gather_records(b)[0], b)
     comm.close()
     assert _lib.lib().rmr_stream_owner(5, 4) == 1
+
+
+def test_file_transport_second_communicator_never_reads_stale_records(tmp_path):
+    """Two communicators, one after the other, on ONE directory (a rank restarted after a crash, a caller-supplied
+    path): the files of the first (left behind: it is never closed before the second runs) must not be read by the
+    second, whose sequence numbers start at 0 again.  A clean close of every communicator removes the directory."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from rm_radar_amd import dist as rd
+    os.environ["TMPDIR"] = str(tmp_path)
+    uid = rd.Comm.unique_id("file")
+    path = uid.split(b"\0")[0].decode()
+
+    def session(tag, rounds, delay_rank1):
+        comms, res = [None, None], [None, None]
+
+        def run(rank):
+            if rank == 1 and delay_rank1:
+                import time
+                time.sleep(0.3)      # rank 0 is already polling for rank 1's file when rank 1 arrives
+            comms[rank] = rd.Comm("file", rank, 2, uid)
+            got = []
+            for k in range(rounds):
+                mine = np.full((2, rd.RECORD_WORDS), tag * 1000 + k * 10 + rank, np.int32)
+                got.append(comms[rank].all_gather_records(mine))
+            res[rank] = got
+        th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(60)
+        for rank in range(2):
+            for k in range(rounds):
+                for src in range(2):
+                    assert (res[rank][k][src] == tag * 1000 + k * 10 + src).all(), (tag, rank, k, src)
+        return comms
+
+    first = session(1, 3, False)          # "crashed": its last files stay in the directory
+    assert any(n.startswith("e0.") for n in os.listdir(path))
+    second = session(2, 3, True)
+    assert any(n.startswith("e1.") for n in os.listdir(path))
+
+    def close_all(comms):
+        th = [threading.Thread(target=c.close) for c in comms]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(30)
+    close_all(second)
+    assert os.path.isdir(path) and not any(n.startswith("e1.") for n in os.listdir(path))
+    close_all(first)
+    assert not os.path.exists(path)
