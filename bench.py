@@ -169,6 +169,30 @@ def make_inputs(args, rank):
     return images, clouds, rects
 
 
+def step_parity_leg(args, rmr, rdet, frames, forced, clouds, local):
+    """Part of the cpu_baseline leg (the only place bench.py touches the oracle, and only as the checker): ONE more step
+    of the timed configuration on a fresh Locator, compared with the CPU oracle frame by frame -- located XYZ / presence
+    of every robot (<= 1e-3 m) and the robot assembly on the step's own armor heads (bit-exact); tests/step_parity.py,
+    the same check tests/test_gpu_bench_step.py runs.  Outside every timed region."""
+    import oracle
+    import scenes
+    import step_parity
+    size = frame_size(args)
+    loc = rmr.Locator(size[0], size[1], intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=local,
+                      max_frames=args.batch)
+    try:
+        robots, counts = rmr.run_batch(rdet, loc, frames, None, forced)
+        cpu = step_parity.oracle_locator(oracle, size, intrinsic(args), scenes.SAMPLE_L2C)
+        stat = step_parity.check_step(oracle, rmr, rdet, cpu, robots, counts, clouds, forced)
+        return True, {k: (round(v, 9) if isinstance(v, float) else v) for k, v in stat.items()}
+    except AssertionError as e:
+        return False, {"error": str(e)[:300]}
+    except Exception as e:  # noqa: BLE001 -- a broken checker must not cost the bench line
+        return False, {"error": f"checker failed: {type(e).__name__}: {e}"[:300]}
+    finally:
+        loc.close()
+
+
 def cpu_baseline(args, packs, images, clouds, rects):
     """The same frame on the host CPU: C oracle (pre / decode+NMS / locate) + PyTorch-CPU fp32
     YOLOv8m (oneDNN) standing in for ONNX-Runtime-CPU + PCL, which this image lacks."""
@@ -378,14 +402,14 @@ def main(argv=None):
     # the frames stay in the same HBM buffers from step to step: their descriptors (64 rmr_image, the
     # cloud pointer table) are marshalled once, as a C++ host would keep them, not rebuilt by 64 x 2
     # Python attribute round trips inside every step
-    frames = rmr.FrameBatch(img_list, cloud_list)
+    frames_fb = rmr.FrameBatch(img_list, cloud_list)
     forced = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(B, -1, 4))
 
     def step():
         # one native call in the reference's order (sample_radar.h:106-127): update + cluster of
         # the 64 frames on a helper thread while detect runs, join, then one batched search
         t0 = time.perf_counter()
-        robots, counts = rmr.run_batch(rdet, loc, frames, None, forced)
+        robots, counts = rmr.run_batch(rdet, loc, frames_fb, None, forced)
         t3 = time.perf_counter()
         block = R.gather(rd.pack_records(robots, counts, cap, rank, cap))
         t4 = time.perf_counter()
@@ -551,6 +575,12 @@ def main(argv=None):
             "per_rank_frames_per_s": [round(B * args.steps / t, 2) for t in per_rank_dt],
             "located_last_step": n_located,
         }
+
+    # ---- the timed configuration checked against the oracle (part of the cpu_baseline leg; needs rdet alive) ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and S == 1:
+        result["parity_checked"], result["parity"] = step_parity_leg(args, rmr, rdet, frames_fb, forced, clouds, local)
+    elif rank == 0:
+        result["parity_checked"], result["parity"] = False, {"skipped": "runs with one rank, one stream and the cpu_baseline leg"}
 
     # ---- batch-1 latency (p50), host inputs: H2D inside the timed region ----
     if rank == 0 and not args.no_latency:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RMR_ABI_VERSION 4
+#define RMR_ABI_VERSION 5
 
 typedef int rmr_status;
 enum {
@@ -279,6 +279,12 @@ rmr_status rmr_robot_detector_detect_batch(rmr_robot_detector* rd, const rmr_ima
                                            int n_frames, const int* forced_crops,
                                            int forced_per_frame, rmr_robot* out, int* n_out,
                                            int cap);
+/* Parity hook: what the networks of the LAST detect / detect_batch / pipeline call handed to postprocess.  stage 0 = the
+ * car network (one image per frame), 1 = the armor network (one image per non-empty car crop, frames in order, cars in
+ * order).  Copies images [first, first + n) as HOST f32 [n][4 + classes][anchors] with their letterbox parameters
+ * (pp may be NULL); n_last (may be NULL) receives the number of images of that call; n = 0 only asks for it. */
+rmr_status rmr_robot_detector_read_heads(rmr_robot_detector* rd, int stage, int first, int n, float* out,
+                                         rmr_preparam* pp, int* n_last);
 /* host-side pieces, exposed for parity tests (robot.cpp:41-74, detector.cpp:324-349, 427-454) */
 rmr_status rmr_robot_set_detection(rmr_robot* r, const rmr_detection* car,
                                    const rmr_detection* armors, int n_armors);

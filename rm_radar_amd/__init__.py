@@ -367,6 +367,8 @@ class RobotDetector:
         cfg.max_frames = max_frames
         cfg.precision = {"f16": 0, "fp8": 1}[precision]
         self.max_cars = max_cars
+        self.armor_classes = armor_classes
+        self.input_size = (int(input_width), int(input_height))
         self._h = C.c_void_p()
         check(lib().rmr_robot_detector_create(C.byref(cfg), C.byref(self._h)))
 
@@ -406,6 +408,19 @@ class RobotDetector:
         check(lib().rmr_robot_detector_detect_batch(self._h, arr, n, _lib.ip(fc) if fc is not None else None,
                                                     per, out, _lib.ip(counts), cap))
         return out, counts
+
+    def read_heads(self, stage, first=0, n=None):
+        """Parity hook (rmr_robot_detector_read_heads): the network output of images [first, first + n) of the LAST call's
+        car (stage 0) or armor (stage 1) batch -- f32 [n, 4 + classes, anchors] -- and their PreParams."""
+        last = C.c_int()
+        check(lib().rmr_robot_detector_read_heads(self._h, stage, 0, 0, None, None, C.byref(last)))
+        n = last.value - first if n is None else n
+        ch = 5 if stage == 0 else 4 + self.armor_classes
+        out = np.empty((n, ch, 8400 * self.input_size[0] * self.input_size[1] // (640 * 640)), np.float32)
+        pps = (PreParam * max(n, 1))()
+        if n > 0:
+            check(lib().rmr_robot_detector_read_heads(self._h, stage, first, n, _lib.fp(out), pps, None))
+        return out, list(pps)[:n]
 
     def detect_batch(self, images, forced_crops=None) -> List[List[Robot]]:
         out, counts = self.detect_batch_raw(images, forced_crops)

@@ -158,6 +158,7 @@ SYMBOLS = {
     "rmr_robot_detector_detect": (C.c_int, [_vp, _P(Image), _P(Robot), _ip, C.c_int]),
     "rmr_robot_detector_detect_batch": (C.c_int, [_vp, _P(Image), C.c_int, _ip, C.c_int,
                                                   _P(Robot), _ip, C.c_int]),
+    "rmr_robot_detector_read_heads": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _P(PreParam), _ip]),
     "rmr_robot_set_detection": (C.c_int, [_P(Robot), _P(Detection), _vp, C.c_int]),
     "rmr_compute_iou": (C.c_float, [_fp, _fp]),
     "rmr_group_robots": (C.c_int, [_P(Robot), C.c_int, C.c_float, _P(Robot), _ip]),

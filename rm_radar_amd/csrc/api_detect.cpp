@@ -109,6 +109,15 @@ rmr_status rmr_robot_detector_detect_batch(rmr_robot_detector* rd, const rmr_ima
     });
 }
 
+rmr_status rmr_robot_detector_read_heads(rmr_robot_detector* rd, int stage, int first, int n, float* out, rmr_preparam* pp,
+                                         int* n_last) {
+    return guarded([&] {
+        if (!rd || (stage != 0 && stage != 1)) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_robot_detector_read_heads: bad detector / stage");
+        const int m = rd->impl.stage(stage).read_heads(first, n, out, pp);
+        if (n_last) *n_last = m;
+    });
+}
+
 // One layer through the conv engine with host f32 tensors (parity tests of the kernel).
 rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, const float* wt, const float* bias,
                       int cout, int kh, int kw, int stride, int pad, int silu, const float* residual, float* y,

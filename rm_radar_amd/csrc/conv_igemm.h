@@ -135,7 +135,11 @@ void launch_conv_g32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
 // the fp8 form (conv_t32f8.hip): e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4, f16 output
 int conv_t32f8_num_tiles();
 ConvTile conv_t32f8_tile(int id);
-bool conv_t32f8_supported(const ConvArgs& a, int tile);  // tile < 0: any
+bool conv_t32f8_supported(const ConvArgs& a, int tile);  // tile < 0: the layer SHAPE only (no tile geometry)
+// plan time: whether at least one tile runs a 3x3 / stride-1 layer of this width on W-wide maps (N divisible by a tile's
+// channel count, the halo rows in the tile's LDS slots) -- the planner gives a layer e4m3 operands only then; returns the
+// first such tile, -1 if none
+int conv_t32f8_first_tile(int cout_pad, int W);
 void launch_conv_t32f8(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
 void launch_quant_f8(DeviceCtx& ctx, hipStream_t stream, const __half* in, int cs, int co, int C, unsigned char* out, int pitch, long npix);
 void pack_conv_weights_t32f8(const __half* packed, int cout_pad, int cin, int Kp, std::vector<unsigned char>& out, std::vector<float>& scale);

@@ -585,13 +585,22 @@ int f8_lds_bytes(const T32F8Tile& t, int W, int cout_pad) { return 2 * f8_rows(t
 int conv_t32f8_num_tiles() { return kNumT32F8Tiles; }
 ConvTile conv_t32f8_tile(int id) { return ConvTile{kT32F8Tiles[id].bm, kT32F8Tiles[id].bn, 64}; }
 
+static bool f8_tile_fits(const T32F8Tile& t, int cout_pad, int W) {
+    const int na = f8_rows(t.bm, W) / 16;
+    return cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && f8_lds_bytes(t, W, cout_pad) <= 160 * 1024 / t.wgs_per_cu;
+}
+
+int conv_t32f8_first_tile(int cout_pad, int W) {
+    for (int i = 0; i < kNumT32F8Tiles; ++i)
+        if (f8_tile_fits(kT32F8Tiles[i], cout_pad, W)) return i;
+    return -1;
+}
+
 bool conv_t32f8_supported(const ConvArgs& a, int tile) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 16 || a.Cin < 32) return false;
     if (a.Ho != a.H || a.Wo != a.W || a.pre || a.in_slab_c || a.out_slab_c || !a.wt8 || !a.in8 || !a.wscale) return false;
     if (tile < 0) return true;
-    const T32F8Tile& t = kT32F8Tiles[tile];
-    const int na = f8_rows(t.bm, a.W) / 16;
-    return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && f8_lds_bytes(t, a.W, a.Cout_pad) <= 160 * 1024 / t.wgs_per_cu;
+    return f8_tile_fits(kT32F8Tiles[tile], a.Cout_pad, a.W);
 }
 
 void launch_quant_f8(DeviceCtx& ctx, hipStream_t stream, const __half* in, int cs, int co, int C, unsigned char* out, int pitch, long npix) {

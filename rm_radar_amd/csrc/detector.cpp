@@ -98,6 +98,7 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
     if (n > cfg_.max_batch_size)
         fail(RMR_ERR_CAPACITY, "Detector: batch of %d exceeds max_batch_size %d", n, cfg_.max_batch_size);
     ctx_.use();
+    last_n_ = n;
     // the pinned descriptor block is reused: make sure the previous call's copy is done
     RMR_HIP(hipStreamSynchronize(stream_));
     for (int i = 0; i < n; ++i) {
@@ -194,6 +195,19 @@ void Detector::infer(const rmr_image* imgs, const int* crops, int n, float* net_
     RMR_HIP(hipStreamSynchronize(stream_));
     if (pp)
         for (int i = 0; i < n; ++i) pp[i] = pp_pin_.p[i];
+}
+
+int Detector::read_heads(int first, int n, float* out, rmr_preparam* pp) {
+    if (n == 0) return last_n_;
+    if (first < 0 || n < 0 || first + n > last_n_ || !out)
+        fail(RMR_ERR_INVALID_ARGUMENT, "read_heads: images [%d, %d) are not inside the last call's %d", first, first + n, last_n_);
+    ctx_.use();
+    const size_t per = (size_t)net_->channels() * net_->anchors();
+    RMR_HIP(hipMemcpyAsync(out, net_->output() + (size_t)first * per, (size_t)n * per * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipStreamSynchronize(stream_));
+    if (pp)
+        for (int i = 0; i < n; ++i) pp[i] = pp_pin_.p[first + i];
+    return last_n_;
 }
 
 // ---- RobotDetector -------------------------------------------------------------------------------------

@@ -39,6 +39,10 @@ class Detector {
     // the same on frames already resident on the device; descs carry src/crop only
     void detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out);
 
+    // Parity hook: images [first, first + n) of the LAST call's network output ([4 + classes][anchors] f32 each, the
+    // tensor handed to postprocess) and their letterbox parameters; returns the number of images of that call
+    int read_heads(int first, int n, float* out, rmr_preparam* pp);
+
     Yolov8& net() { return *net_; }
     hipStream_t stream() { return stream_; }
     DeviceCtx& ctx() { return ctx_; }
@@ -54,6 +58,7 @@ class Detector {
     FrameStage stage_;
     static constexpr int kHeadRows = 64;  // rows per image fetched with the counts
     int det_cap_ = 0;
+    int last_n_ = 0;  // images of the last enqueue()
     DevBuf<LetterboxDesc> descs_dev_;
     DevBuf<rmr_preparam> pp_dev_;
     DevBuf<uint8_t> post_scratch_;
@@ -69,6 +74,7 @@ class RobotDetector {
    public:
     explicit RobotDetector(const rmr_robot_detector_cfg& cfg);
     size_t arena_bytes() { return car_->net().arena_bytes() + armor_->net().arena_bytes(); }
+    Detector& stage(int i) { return i == 0 ? *car_ : *armor_; }
     // RobotDetector::detect (detector.cpp:413-455), batched over frames
     // after_cars (optional) runs as soon as stage 1 is known -- the car boxes per frame, before the
     // armor stage is enqueued; car_index_out (optional, [n_frames][cap]) names the car each output

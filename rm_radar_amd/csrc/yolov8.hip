@@ -209,7 +209,15 @@ void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act
     op.out = out;
     // fp8 plan: a 3x3 / stride-1 layer with e4m3 weights reads an e4m3 copy of its input, written just before it
     // (the layers between keep f16 activations: the copy is one extra pass over a tensor the conv reads nine times)
-    if (cw.w8.p && stride == 1 && !in_is_input && !pre && in.h == out.h && in.w == out.w) {
+    // ... and only where an e4m3 tile exists for the layer's width on maps this wide (tile channel counts are 64 / 96 / 192 /
+    // 256 and the halo rows must fit a tile's LDS slots): a 80- or 160-channel layer of a wider pack, or a 96-channel layer
+    // on 240-wide maps, stays f16 -- no e4m3 weights, no quantiser pass -- instead of failing at its first forward
+    const bool f8_layer = cw.w8.p && stride == 1 && !in_is_input && !pre && in.h == out.h && in.w == out.w;
+    if (f8_layer && conv_t32f8_first_tile(cw.cout_pad, in.w) < 0) {
+        convs_[widx].w8.release();
+        convs_[widx].wscale.release();
+    }
+    if (cw.w8.p && f8_layer) {
         Op q{};
         q.kind = OP_QUANT;
         q.in = in;
@@ -979,7 +987,9 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
                 break;
             }
             if (!autotune_) {
-                if (a.in_slab_c || a.out_slab_c) {
+                if (a.in8) {  // fp8 plan without tuning: the first e4m3 tile that fits (the planner checked that one does)
+                    launch_conv_t32f8(ctx_, s, a, conv_t32f8_first_tile(a.Cout_pad, a.W));
+                } else if (a.in_slab_c || a.out_slab_c) {
                     int v = 0;
                     while (!conv_pw_supported(a, v)) ++v;  // the planner checked that one exists
                     launch_conv_pw(ctx_, s, a, v);

@@ -1,0 +1,94 @@
+"""The headline step itself, checked: bench.py's inputs (BASELINE configs[2]: 64 synthetic 640x640 frames + 30k-point
+clouds, K = 4 injected crops per frame) through the one native call the bench times (rmr_pipeline_run_batch ->
+update_cluster_batch over 64 frames -> two-stage detect at 64 / 256 images -> search_batch), compared frame by frame with
+the CPU oracle (tests/step_parity.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+import step_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bench():
+    import bench as B
+    return B
+
+
+@pytest.fixture(scope="module")
+def step_inputs(bench):
+    args = bench.parse([])   # the driver's defaults: batch 64, crops 4, 30k points, 640x640
+    assert (args.batch, args.crops, args.points, bench.frame_size(args)) == (64, 4, 30000, (640, 640))
+    images, clouds, rects = bench.make_inputs(args, 0)
+    return args, images, clouds, rects
+
+
+@pytest.fixture(scope="module")
+def packs(tmp_path_factory):
+    from rm_radar_amd import weights as W
+    d = tmp_path_factory.mktemp("step_packs")
+    car, armor = str(d / "car.rmrw"), str(d / "armor.rmrw")
+    W.make_synthetic_pack(car, "m", 1, seed=1, cls_bias=-6.0)      # bench.py's packs
+    W.make_synthetic_pack(armor, "m", 12, seed=2, cls_bias=-6.0)
+    return car, armor
+
+
+def _run_steps(bench, oracle, step_inputs, packs, n_steps, device_inputs, **det_kw):
+    import torch
+
+    import rm_radar_amd as rmr
+    args, images, clouds, rects = step_inputs
+    B, K, size = args.batch, args.crops, bench.frame_size(args)
+    rdet = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=K, opt_cars=K, max_frames=B, **det_kw)
+    loc = rmr.Locator(size[0], size[1], bench.intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), max_frames=B)
+    if device_inputs:   # as the bench: frames and clouds resident in HBM, descriptors marshalled once
+        d_images, d_clouds = torch.from_numpy(images).cuda(), torch.from_numpy(clouds).cuda()
+        frames = rmr.FrameBatch([d_images[f] for f in range(B)], [d_clouds[f] for f in range(B)])
+    else:
+        frames = rmr.FrameBatch(list(images), list(clouds))
+    forced = np.ascontiguousarray(rects, np.int32)
+    cpu = step_parity.oracle_locator(oracle, size, bench.intrinsic(args), scenes.SAMPLE_L2C)
+    stats = []
+    for _ in range(n_steps):
+        robots, counts = rmr.run_batch(rdet, loc, frames, None, forced)
+        stats.append(step_parity.check_step(oracle, rmr, rdet, cpu, robots, counts, clouds, forced,
+                                            armor_conf=det_kw.get("armor_conf_thresh", 0.5)))
+    rdet.close()
+    loc.close()
+    return stats
+
+
+def test_headline_step_matches_oracle(bench, oracle, step_inputs, packs):
+    """Three consecutive steps of the bench's own workload on ONE stream (the Locator's background and depth ring carry
+    over from step to step, as in the timed loop): located XYZ / presence of every robot of every frame against an
+    oracle.Locator fed the same 3 x 64 clouds in order, robot assembly against the oracle on the step's own armor heads."""
+    stats = _run_steps(bench, oracle, step_inputs, packs, 3, device_inputs=True)
+    for s in stats:
+        assert s["frames"] == 64 and s["assembly_frames"] == 64
+        assert s["robots"] >= 64
+        assert s["max_xyz_err_m"] <= 1e-3
+    # frames 2.. of the first step carry robots in front of the background: most injected rects are located
+    assert stats[0]["located"] >= 100 and stats[1]["located"] >= 100
+
+
+def test_headline_step_with_labels(bench, oracle, step_inputs, packs):
+    """The bench's packs score every class near sigmoid(-6), so at the default 0.5 no armor survives and every robot of the
+    step above is unlabelled.  The same step with the armor threshold inside the score range of the step's heads: armors
+    survive decode + NMS, robots get labels, same-label robots of a frame are grouped -- still bit-equal to the oracle's
+    assembly on the GPU's heads, from host-resident frames this time (the staging path of detector.cu:388)."""
+    import rm_radar_amd as rmr
+    args, images, clouds, rects = step_inputs
+    # where the threshold has to be: the scores of a few crops of the step
+    probe = rmr.Detector(packs[1], 12, (640, 640), 8)
+    heads, _ = probe.infer([images[f] for f in range(8)], crops=[tuple(int(v) for v in rects[f, 0]) for f in range(8)])
+    probe.close()
+    best = np.sort(heads[:, 4:].max(1).reshape(-1))
+    t = float(best[-40])   # a few dozen candidate anchors per 8 crops
+    assert 0.0 < t < 0.5
+    stats = _run_steps(bench, oracle, step_inputs, packs, 1, device_inputs=False, armor_conf_thresh=t)
+    s = stats[0]
+    assert s["assembly_frames"] == 64 and s["labelled"] >= 16 and s["armors"] >= s["labelled"]

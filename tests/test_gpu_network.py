@@ -445,3 +445,38 @@ def test_fp8_plan_matches_its_oracle_and_stays_close_to_f16(rmr, packs, images):
             kept += any(g["label"] == w["label"] and netutil.iou_xywh(tuple(g)[:4], tuple(w)[:4]) >= 0.8 for g in d8)
     print(f"confident f16 detections kept by the fp8 plan: {kept} of {total}")
     assert total == 0 or kept >= 0.5 * total
+
+
+def test_fp8_plan_decides_per_layer_and_runs_untuned(rmr, packs, images, tmp_path, monkeypatch):
+    """The fp8 plan gives a layer e4m3 operands only where an e4m3 tile exists for its width on maps of its size
+    (conv_t32f8_first_tile at plan time): a yolov8x-width pack has 160-channel 3x3 layers no tile divides -- they stay f16,
+    without weights or quantiser pass, the 320- / 640-channel ones run e4m3 -- instead of failing at the first forward.
+    And RMR_AUTOTUNE=0 runs the e4m3 layers on e4m3 tiles (it used to fall through to the f16 kernels behind the
+    quantiser passes)."""
+    from rm_radar_amd import weights as W
+    xpack = W.make_synthetic_pack(str(tmp_path / "x.rmrw"), "x", 12, seed=5, cls_bias=-3.0)
+    img = images[0]
+    d8 = rmr.Detector(xpack, 12, (1920, 1080), 1, precision="fp8")
+    got8, _ = d8.infer([img])
+    d8.close()
+    d16 = rmr.Detector(xpack, 12, (1920, 1080), 1)
+    got16, _ = d16.infer([img])
+    d16.close()
+    assert np.isfinite(got8).all()
+    diff = np.abs(got8[:, :4] - got16[:, :4])
+    assert diff.max() > 1e-3, "no layer of the x pack ran in e4m3"
+    assert diff.mean() <= 6.0, f"fp8 plan of the x pack is {diff.mean():.2f} px from its f16 plan"
+    # untuned fp8 on the m pack: e4m3 kernels, close to the tuned fp8 plan, not the f16 plan
+    tuned = rmr.Detector(packs[1], 12, (1920, 1080), 3, precision="fp8")
+    want8, _ = tuned.infer(images)
+    tuned.close()
+    f16 = rmr.Detector(packs[1], 12, (1920, 1080), 3)
+    want16, _ = f16.infer(images)
+    f16.close()
+    monkeypatch.setenv("RMR_AUTOTUNE", "0")
+    untuned = rmr.Detector(packs[1], 12, (1920, 1080), 3, precision="fp8")
+    got, _ = untuned.infer(images)
+    untuned.close()
+    to8, to16 = np.abs(got[:, :4] - want8[:, :4]).mean(), np.abs(got[:, :4] - want16[:, :4]).mean()
+    print(f"untuned fp8 vs tuned fp8: {to8:.3f} px; vs f16: {to16:.3f} px")
+    assert to8 < to16 and to8 <= 1.5
