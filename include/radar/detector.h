@@ -40,12 +40,23 @@ inline rmr_image to_c(const ImageView& v) {
 }
 }  // namespace detail
 
-// detector.h:70-77: an image or a container of images
+namespace detail {
+// one image: this library's view, or (with OpenCV) the reference's cv::Mat
 template <typename T>
-concept ImageOrImages = std::is_same_v<std::decay_t<T>, ImageView> || requires(T t) {
+inline constexpr bool is_image_v = std::is_same_v<std::decay_t<T>, ImageView>
+#ifdef RADAR_HAVE_OPENCV
+                                   || std::is_same_v<std::decay_t<T>, cv::Mat>
+#endif
+    ;
+}  // namespace detail
+
+// detector.h:70-77: an image (cv::Mat / ImageView) or a container of images (std::vector<cv::Mat>, std::span<cv::Mat>, ...)
+template <typename T>
+concept ImageOrImages = detail::is_image_v<T> || requires(T t) {
     typename std::decay_t<T>::value_type;
     { t.begin() } -> std::same_as<typename std::decay_t<T>::iterator>;
     { t.end() } -> std::same_as<typename std::decay_t<T>::iterator>;
+    requires detail::is_image_v<typename std::decay_t<T>::value_type>;
 };
 
 class Detector {
@@ -77,10 +88,12 @@ class Detector {
     // detector.h:117-134
     template <ImageOrImages T>
     auto detect(T&& input) noexcept {
-        if constexpr (std::is_same_v<std::decay_t<T>, ImageView>) {
-            return run(std::span<const ImageView>(&input, 1))[0];
-        } else {
-            std::vector<ImageView> v(input.begin(), input.end());
+        if constexpr (detail::is_image_v<T>) {   // std::vector<Detection>
+            const ImageView one(input);
+            return run(std::span<const ImageView>(&one, 1))[0];
+        } else {                                 // std::vector<std::vector<Detection>>
+            std::vector<ImageView> v;
+            for (const auto& im : input) v.emplace_back(im);
             return run(v);
         }
     }
@@ -133,6 +146,10 @@ class RobotDetector {
     RobotDetector(const RobotDetector&) = delete;
     RobotDetector& operator=(const RobotDetector&) = delete;
 
+#ifdef RADAR_HAVE_OPENCV
+    // detector.h:184, the reference's own signature
+    std::vector<Robot> detect(const cv::Mat& image) { return detect(ImageView(image)); }
+#endif
     // detector.cpp:413-455
     std::vector<Robot> detect(const ImageView& image) {
         const rmr_image ci = detail::to_c(image);

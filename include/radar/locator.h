@@ -22,8 +22,9 @@ class Locator {
         rmr_locator_cfg c;
         rmr_locator_cfg_default(&c);
         c.image_width = image_width, c.image_height = image_height;
-        for (int i = 0; i < 9; ++i) c.intrinsic[i] = intrinsic[i];
-        for (int i = 0; i < 16; ++i) c.lidar_to_camera[i] = lidar_to_camera[i], c.world_to_camera[i] = world_to_camera[i];
+        for (int i = 0; i < 9; ++i) c.intrinsic[i] = detail::mat_at(intrinsic, i);
+        for (int i = 0; i < 16; ++i)
+            c.lidar_to_camera[i] = detail::mat_at(lidar_to_camera, i), c.world_to_camera[i] = detail::mat_at(world_to_camera, i);
         c.zoom_factor = zoom_factor;
         c.queue_size = (int)queue_size;
         c.min_depth_diff = min_depth_diff, c.max_depth_diff = max_depth_diff;
@@ -37,9 +38,18 @@ class Locator {
     Locator(const Locator&) = delete;
     Locator& operator=(const Locator&) = delete;
 
+#ifdef RADAR_HAVE_PCL
+    // locator.h:67, the reference's own signature
+    void update(const pcl::PointCloud<pcl::PointXYZ>::Ptr& cloud) noexcept {
+        if (!cloud) std::cerr << "cloud is null." << std::endl;
+        else if (cloud->empty()) std::cerr << "cloud is empty." << std::endl;
+        const CloudView v(cloud);
+        detail::check_or_abort(rmr_locator_update(h_, v.xyz, v.size, v.stride_bytes, RMR_MEM_HOST));
+    }
+#endif
     // locate.cpp:158-220; a null / empty cloud prints the reference's message and returns
     void update(const CloudView& cloud) noexcept {
-        if (!cloud.xyz) std::cerr << "cloud is null." << std::endl;
+        if (!cloud.xyz && cloud.empty()) std::cerr << "cloud is null." << std::endl;
         else if (cloud.empty()) std::cerr << "cloud is empty." << std::endl;
         detail::check_or_abort(rmr_locator_update(h_, cloud.xyz, cloud.size, cloud.stride_bytes,
                                                   cloud.on_device ? RMR_MEM_DEVICE : RMR_MEM_HOST));

@@ -1,0 +1,3 @@
+// TEST-ONLY stand-in: see core.hpp in this directory.
+#pragma once
+#include "core.hpp"

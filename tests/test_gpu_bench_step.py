@@ -71,15 +71,17 @@ def test_headline_step_matches_oracle(bench, oracle, step_inputs, packs):
         assert s["frames"] == 64 and s["assembly_frames"] == 64
         assert s["robots"] >= 64
         assert s["max_xyz_err_m"] <= 1e-3
-    # frames 2.. of the first step carry robots in front of the background: most injected rects are located
-    assert stats[0]["located"] >= 100 and stats[1]["located"] >= 100
+    # frames 2.. of the first step carry robots in front of the background: nearly every robot that survives the per-label
+    # grouping (about 100 of the 256 crops: the synthetic armor network votes for few labels) is located
+    assert stats[0]["located"] >= 64 and stats[1]["located"] >= 64
+    assert all(s["labelled"] >= 32 and s["armors"] >= s["labelled"] for s in stats)
 
 
 def test_headline_step_with_labels(bench, oracle, step_inputs, packs):
-    """The bench's packs score every class near sigmoid(-6), so at the default 0.5 no armor survives and every robot of the
-    step above is unlabelled.  The same step with the armor threshold inside the score range of the step's heads: armors
-    survive decode + NMS, robots get labels, same-label robots of a frame are grouped -- still bit-equal to the oracle's
-    assembly on the GPU's heads, from host-resident frames this time (the staging path of detector.cu:388)."""
+    """The same step from HOST-resident frames and clouds (the staging path of detector.cu:388) and with a lower armor
+    threshold, placed inside the score range of the step's heads: several times more armors survive decode + NMS, more
+    robots carry labels and more same-label robots of a frame are grouped -- still bit-equal to the oracle's assembly on
+    the GPU's own heads."""
     import rm_radar_amd as rmr
     args, images, clouds, rects = step_inputs
     # where the threshold has to be: the scores of a few crops of the step
@@ -87,8 +89,8 @@ def test_headline_step_with_labels(bench, oracle, step_inputs, packs):
     heads, _ = probe.infer([images[f] for f in range(8)], crops=[tuple(int(v) for v in rects[f, 0]) for f in range(8)])
     probe.close()
     best = np.sort(heads[:, 4:].max(1).reshape(-1))
-    t = float(best[-40])   # a few dozen candidate anchors per 8 crops
-    assert 0.0 < t < 0.5
+    t = min(0.35, float(best[-400]))   # a few hundred candidate anchors per 8 crops
+    assert 0.0 < t
     stats = _run_steps(bench, oracle, step_inputs, packs, 1, device_inputs=False, armor_conf_thresh=t)
     s = stats[0]
     assert s["assembly_frames"] == 64 and s["labelled"] >= 16 and s["armors"] >= s["labelled"]
