@@ -50,6 +50,22 @@ HBM_PEAK_TBS = 8.0              # MI355X_MICROARCH.md: 8 TB/s (6.3 achievable)
 # what a chip-filling loop of nothing but v_mfma_f32_32x32x16_f16 delivers on random f16 operands before the
 # power limit clocks it down (tools/microbench/mfma_power.hip, profiles/r02_mfma_power.txt); zeros: 2400
 F16_POWER_LIMITED_TFLOPS = 1650.0
+FP8_DENSE_PEAK_TFLOPS = 5000.0  # MI355X_MICROARCH.md: ~5 PF dense fp8 MFMA (the e4m3 layers of the fp8 plan run on this pipe)
+
+# the tag at the end of a per-layer profile name ("conv n256 M409600 N192 K1728 k3 s1 g10") -> the kernel template it is an
+# instantiation of; tag + number = one instantiation = one symbol in a rocprofv3 kernel trace
+KERNEL_OF_TAG = {"g": "conv_t32_kernel (csrc/conv_t32.hip)", "m": "conv_g32_kernel (csrc/conv_g32.hip)",
+                 "p": "conv_pw_kernel (csrc/conv_pw.hip)", "w": "conv_ws_kernel (csrc/conv_ws.hip)",
+                 "v": "conv_ws_s2_kernel (csrc/conv_ws_s2.hip)", "d": "conv_dma_kernel (csrc/conv_dma.hip)",
+                 "t": "conv_igemm_kernel (csrc/conv_igemm.hip)", "h": "conv_halo_kernel (csrc/conv_halo.hip)",
+                 "x": "conv_direct_kernel (csrc/conv_direct.hip)", "f": "conv_t32f8_kernel (csrc/conv_t32f8.hip)",
+                 "s": "conv_stem_kernel (csrc/conv_stem.hip)", "q": "conv_wino_kernel (csrc/conv_wino.hip)"}
+
+
+def instantiation_of(layer_name):
+    """'conv n256 M409600 N192 K1728 k3 s1 g10' -> 'g10' ('stem+letterbox' -> 'stem'; split-K 'd44/2' -> 'd44')"""
+    tag = layer_name.split()[-1]
+    return "stem" if tag.startswith("stem") else tag.split("/")[0]
 
 
 def source_hash():
@@ -481,33 +497,58 @@ def main(argv=None):
                 stage_ms["other"] += ms
         stage_ms = {k: round(v, 3) for k, v in stage_ms.items()}
 
-    # ---- 5. the step's inputs over PCIe, on their own -----------------------------------------------------
-    h2d_ms = None
-    if rank == 0:
-        p_img = torch.from_numpy(images).pin_memory()
-        p_cld = torch.from_numpy(clouds).pin_memory()
-        for _ in range(2):
-            d_images.copy_(p_img, non_blocking=True)
-            d_clouds.copy_(p_cld, non_blocking=True)
-        torch.cuda.synchronize()
+    # ---- 5. host inputs: the step's frames + clouds over PCIe.  (a) the copy on its own; (b) the loop a capture host
+    # would run: step i + 1's inputs travel from page-locked buffers into the other slot of an upload ring
+    # (rmr_upload_*, its own copy stream) while step i computes -> value_incl_h2d.  Never `value`.
+    h2d_ms, incl_h2d = None, None
+    if rank == 0 and S == 1:
+        p_img, p_cld = rmr.PinnedArray(images.shape, np.uint8), rmr.PinnedArray(clouds.shape, np.float32)
+        p_img.a[...] = images
+        p_cld.a[...] = clouds
+        ring = rmr.UploadRing(2, images.nbytes + clouds.nbytes + 4096, device=local)
+        fbs = []
+        for slot in range(2):   # the slots' addresses never change: descriptors marshalled once per slot
+            di, dc = ring.begin(slot, [p_img.a, p_cld.a])
+            ring.wait(slot)
+            fbs.append(rmr.FrameBatch([di[f] for f in range(B)], [dc[f] for f in range(B)]))
         t0 = time.perf_counter()
         for _ in range(5):
-            d_images.copy_(p_img, non_blocking=True)
-            d_clouds.copy_(p_cld, non_blocking=True)
-        torch.cuda.synchronize()
+            ring.begin(0, [p_img.a, p_cld.a])
+            ring.wait(0)
         h2d_ms = (time.perf_counter() - t0) / 5 * 1e3
-        del p_img, p_cld
+        n_h = max(args.steps, 10)
+
+        def host_step(i):
+            ring.begin((i + 1) % 2, [p_img.a, p_cld.a])   # next step's inputs start travelling ...
+            ring.wait(i % 2)                               # ... this step's have landed long ago
+            rmr.run_batch(rdet, loc, fbs[i % 2], None, forced)
+        ring.begin(0, [p_img.a, p_cld.a])
+        for i in range(2):
+            host_step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2, 2 + n_h):
+            host_step(i)
+        ring.wait(n_h % 2)
+        torch.cuda.synchronize()
+        incl_h2d = {"steps": n_h, "value": round(B * n_h / (time.perf_counter() - t0), 2), "unit": "frames/s",
+                    "how": "inputs of step i+1 copied from pinned host buffers on the upload ring's copy stream while step i runs"}
+        ring.close()
+        del fbs
+        p_img.close()
+        p_cld.close()
 
     n_located = int(((block.view(-1, 12)[:, 9] & 2) != 0).sum().item()) if block.numel() else 0
     # HBM traffic per conv launch: PMC counters cannot be read from inside this process; the figure comes from
     # rocprofv3 --pmc passes over this same command (tools/round_profile.sh) and is only as fresh as the kernel
     # sources it was measured on: the file records their hash, a mismatch is reported as stale
-    traffic, traffic_src, traffic_stale = None, None, None
+    traffic, traffic_src, traffic_stale, dom_traffic, dom_symbol = None, None, None, None, None
     for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_conv_traffic.json")), reverse=True):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if B == 64 and K == 4 and size == (640, 640):
                 traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/" + name
+                dom_traffic, dom_symbol = pm.get("dominant_traffic_bytes_per_launch"), pm.get("dominant_kernel")
                 traffic_stale = pm.get("source_hash") != source_hash()
             break
         except (OSError, KeyError, ValueError):
@@ -520,18 +561,37 @@ def main(argv=None):
                 "bytes": sum(v["bytes"] for v in convs.values()), "launches": sum(v["launches"] for v in convs.values())}
         ach = conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0
         psteps = max(args.profile_steps, 1)
+        # the e4m3 layers of the fp8 plan run on the 5 PF pipe: the peak of a mixed set of launches is FLOP-weighted
+        # (the time the set needs when every launch runs at its own pipe's peak)
+        def peak_of(vs):
+            f8 = sum(v["flops"] for k, v in vs if instantiation_of(k).startswith("f"))
+            f16 = sum(v["flops"] for k, v in vs) - f8
+            return (f8 + f16) / (f16 / F16_DENSE_PEAK_TFLOPS + f8 / FP8_DENSE_PEAK_TFLOPS) if f8 + f16 > 0 else F16_DENSE_PEAK_TFLOPS
+        family_peak = peak_of(convs.items())
+        # the dominant kernel = the template instantiation (one symbol of a kernel trace) with the most time in a step
+        inst = {}
+        for k, v in convs.items():
+            e = inst.setdefault(instantiation_of(k), {"total_ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "layers": []})
+            for f in ("total_ms", "flops", "bytes", "launches"):
+                e[f] += v[f]
+            e["layers"].append(k)
+        dom_tag, dom = max(inst.items(), key=lambda kv: kv[1]["total_ms"]) if inst else ("-", None)
+        dom_ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12 if dom and dom["total_ms"] > 0 else 0.0
+        dom_peak = FP8_DENSE_PEAK_TFLOPS if dom_tag.startswith("f") else F16_DENSE_PEAK_TFLOPS
         # every layer against its own bound: the time the chip needs at the MFMA peak or at the HBM peak,
         # whichever is larger; summed over the step
-        bound_ms = sum(max(v["flops"] / (F16_DENSE_PEAK_TFLOPS * 1e12), v["bytes"] / (HBM_PEAK_TBS * 1e12)) * 1e3 for v in convs.values())
+        def pk(k):
+            return (FP8_DENSE_PEAK_TFLOPS if instantiation_of(k).startswith("f") else F16_DENSE_PEAK_TFLOPS) * 1e12
+        bound_ms = sum(max(v["flops"] / pk(k), v["bytes"] / (HBM_PEAK_TBS * 1e12)) * 1e3 for k, v in convs.items())
         top = sorted(convs.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
         layer_roofline = {
-            "peaks": {"mfma_tflops": F16_DENSE_PEAK_TFLOPS, "hbm_tbs": HBM_PEAK_TBS},
+            "peaks": {"mfma_tflops": F16_DENSE_PEAK_TFLOPS, "mfma_fp8_tflops": FP8_DENSE_PEAK_TFLOPS, "hbm_tbs": HBM_PEAK_TBS},
             "bound_ms_per_step": round(bound_ms / psteps, 3), "measured_ms_per_step": round(conv["total_ms"] / psteps, 3),
             "frac": round(bound_ms / conv["total_ms"], 4) if conv["total_ms"] > 0 else None,
             "layers": len(convs),
             "top": [{"layer": k, "launches_per_step": v["launches"] / psteps, "ms_per_step": round(v["total_ms"] / psteps, 3),
                      "tflops": round(v["flops"] / v["total_ms"] / 1e9, 1), "gbs": round(v["bytes"] / v["total_ms"] / 1e6),
-                     "bound": "mfma" if v["flops"] / F16_DENSE_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_TBS / 1e12 else "hbm"}
+                     "bound": "mfma" if v["flops"] / pk(k) >= v["bytes"] / HBM_PEAK_TBS / 1e12 else "hbm"}
                     for k, v in top]}
         result = {
             "metric": "frames/sec detect+locate (640x640 + 30k-pt cloud)",
@@ -552,22 +612,43 @@ def main(argv=None):
                        "frames_per_step_per_gpu": B, "crops_per_frame": K, "points_per_cloud": args.points,
                        "streams_per_gpu": S, "gflop_per_frame": round(flops_frame / 1e9, 3),
                        "activation_arena_gib": round(arena_gib, 2)},
-            "roofline": {"bound": "mfma", "kernel": "conv_* (the convolution launches of a step)", "achieved": round(ach, 2),
-                         "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / F16_DENSE_PEAK_TFLOPS, 4),
-                         "power_limited_peak": F16_POWER_LIMITED_TFLOPS,
-                         "frac_of_power_limited_peak": round(ach / F16_POWER_LIMITED_TFLOPS, 4),
+            # the dominant kernel of a step: ONE template instantiation (one symbol of the rocprofv3 kernel trace)
+            "roofline": {"bound": "mfma",
+                         "kernel": f"{KERNEL_OF_TAG.get(dom_tag[0], 'conv')} instantiation {dom_tag}: the kernel with the most time in a step "
+                                   f"({100 * dom['total_ms'] / conv['total_ms']:.1f} % of the convolution time)" if dom else None,
+                         "achieved": round(dom_ach, 2), "peak": dom_peak, "unit": "TFLOP/s", "frac": round(dom_ach / dom_peak, 4),
+                         # PMC counters cannot be read from inside this process: from the rocprofv3 --pmc passes over this same
+                         # command (tools/round_profile.sh), for the symbol with the most time in that trace
+                         "traffic": dom_traffic, "traffic_kernel_symbol": dom_symbol, "traffic_source": traffic_src,
+                         "traffic_stale": traffic_stale,
+                         "launches_per_step": dom["launches"] / psteps if dom else 0,
+                         "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5) if dom else None,
+                         "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 4) if dom else None,
+                         "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)) if dom else None,
+                         "layers": sorted(dom["layers"]) if dom else [],
+                         "measured_in": f"{psteps} profiled step(s) after the headline loop (HIP events on the detector's stream)"},
+            # every convolution launch of a step together (all instantiations: what rounds 1-2 reported as `roofline`)
+            "roofline_all_conv_launches": {
+                         "bound": "mfma", "kernel": "conv_* (every convolution launch of a step)", "achieved": round(ach, 2),
+                         "peak": round(family_peak, 1), "unit": "TFLOP/s",
+                         "frac": round(ach / family_peak, 4),
+                         "power_limited_peak": F16_POWER_LIMITED_TFLOPS if args.dtype == "f16" else None,
+                         "frac_of_power_limited_peak": round(ach / F16_POWER_LIMITED_TFLOPS, 4) if args.dtype == "f16" else None,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": round(conv["bytes"] / max(conv["launches"], 1)),
                          "launches_per_step": conv["launches"] / psteps,
                          "avg_launch_ms": round(conv["total_ms"] / max(conv["launches"], 1), 5),
                          "algorithmic_gflop_per_launch": round(conv["flops"] / max(conv["launches"], 1) / 1e9, 4),
-                         "measured_in": f"{psteps} profiled step(s) after the headline loop (events on the detector's streams)"},
+                         "by_instantiation": {t: {"ms_per_step": round(e["total_ms"] / psteps, 3), "launches_per_step": e["launches"] / psteps,
+                                                  "tflops": round(e["flops"] / e["total_ms"] / 1e9, 1) if e["total_ms"] > 0 else 0.0}
+                                              for t, e in sorted(inst.items(), key=lambda kv: -kv[1]["total_ms"])[:12]}},
             "layer_roofline": layer_roofline,
             "stage_ms_per_step": stage_ms,
             "steady_state": steady,
             "h2d_ms_per_step": None if h2d_ms is None else round(h2d_ms, 3),
-            "value_incl_h2d": None if h2d_ms is None else round(B * world / (dt / args.steps + h2d_ms * 1e-3), 2),
+            "value_incl_h2d": None if incl_h2d is None else incl_h2d["value"],
+            "host_input_loop": incl_h2d,
+            "value_incl_h2d_not_overlapped": None if h2d_ms is None else round(B * world / (dt / args.steps + h2d_ms * 1e-3), 2),
             "end_to_end_tflops": round(flops_frame * frames / dt / 1e12, 2),
             "host_phase_ms_per_step": {k: round(v / args.steps * 1e3, 2) for k, v in headline_phases.items()},
             "gather": R.gather_via,

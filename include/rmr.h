@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RMR_ABI_VERSION 5
+#define RMR_ABI_VERSION 6
 
 typedef int rmr_status;
 enum {
@@ -380,6 +380,25 @@ rmr_status rmr_pipeline_run_streams(rmr_robot_detector* rd, rmr_locator* const* 
                                     const rmr_image* imgs, const float* const* clouds, const int* n_points,
                                     int stride_bytes, int mem, int n_frames, const int* forced_crops,
                                     int forced_per_frame, rmr_robot* out, int* n_out, int cap);
+
+/* ---------------------------------------------------------------- input staging, throughput mode
+ * The reference uploads inside its cycle: every image is memcpy'd into a mapped pinned buffer that the resize kernel
+ * reads across PCIe (src/detect/detector.cu:388-399, 455-470).  For batches this ring takes the upload out of the
+ * cycle: step i + 1's frames and clouds are copied from the caller's page-locked buffers into device slot (i + 1) %
+ * slots on a copy stream of their own while step i computes; the device addresses go into the rmr_image / cloud
+ * tables of rmr_pipeline_run_batch (mem = RMR_MEM_DEVICE) after rmr_upload_wait. */
+typedef struct rmr_upload rmr_upload;
+/* page-locked host memory (hipHostMalloc): a copy from it is one DMA, from pageable memory it is staged by the driver */
+rmr_status rmr_pinned_alloc(size_t bytes, void** out);
+void rmr_pinned_free(void* p);
+rmr_status rmr_upload_create(int device, int slots, size_t bytes_per_slot, rmr_upload** out);
+void rmr_upload_destroy(rmr_upload* up);
+/* starts the copies of n host blocks into `slot` (packed at 256-byte boundaries; blocks adjacent in host memory
+ * travel as one copy) and returns at once; dev_out[i] = the device address block i will have.  The slot must not be
+ * in use by a running step; RMR_ERR_CAPACITY when the blocks do not fit bytes_per_slot. */
+rmr_status rmr_upload_begin(rmr_upload* up, int slot, const void* const* src, const size_t* bytes, int n, void** dev_out);
+/* blocks the calling thread until the slot's copies have landed (no-op when none is pending) */
+rmr_status rmr_upload_wait(rmr_upload* up, int slot);
 
 /* ---------------------------------------------------------------- per-kernel profile */
 

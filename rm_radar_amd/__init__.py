@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import (CapacityError, DET_DTYPE, DeviceError, InvalidArgument, PreParam, RmrError,
                    check, lib)
 
-__all__ = ["Detector", "RobotDetector", "Locator", "Robot", "PreParam", "preparam", "FrameBatch",
+__all__ = ["Detector", "RobotDetector", "Locator", "Robot", "PreParam", "preparam", "FrameBatch", "UploadRing", "PinnedArray", "DeviceArray",
            "letterbox_geometry", "letterbox", "preprocess", "postprocess", "transpose",
            "conv2d", "pin_plan", "restore_detection", "device_count", "profile", "DET_DTYPE", "RmrError",
            "run_batch", "Tracker", "KalmanFilter", "SingerEKF", "auction", "TRACK_TENTATIVE", "TRACK_CONFIRMED", "TRACK_DELETED",
@@ -615,6 +615,97 @@ class Locator:
 
 
 # ------------------------------------------------------------------------------- profiling
+
+# ------------------------------------------------------------------------------- input staging
+
+class DeviceArray:
+    """A typed view of device memory this package did not get from torch (an UploadRing slot): quacks like the
+    torch CUDA tensors that _as_image / FrameBatch accept (data_ptr, shape, stride in elements, element_size)."""
+    is_cuda = True
+
+    def __init__(self, ptr: int, shape, dtype):
+        self.ptr, self.shape, self.dtype = int(ptr), tuple(int(v) for v in shape), np.dtype(dtype)
+        st, acc = [], 1
+        for n in reversed(self.shape):
+            st.append(acc)
+            acc *= n
+        self._strides = tuple(reversed(st))
+
+    def __getitem__(self, i):
+        """a[i]: the i-th slice along the first axis (a frame of a batch block)."""
+        i = int(i)
+        if not 0 <= i < self.shape[0]:
+            raise IndexError(i)
+        return DeviceArray(self.ptr + i * self._strides[0] * self.dtype.itemsize, self.shape[1:], self.dtype)
+
+    def data_ptr(self):
+        return self.ptr
+
+    def dim(self):
+        return len(self.shape)
+
+    def stride(self, i):
+        return self._strides[i]
+
+    def element_size(self):
+        return self.dtype.itemsize
+
+
+class PinnedArray:
+    """Page-locked host memory (rmr_pinned_alloc) as a numpy array: `.a`.  Copies from it to the GPU are single DMAs
+    that really run asynchronously; a capture pipeline would write its frames straight into such buffers."""
+
+    def __init__(self, shape, dtype):
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * self.dtype.itemsize
+        self._p = C.c_void_p()
+        check(lib().rmr_pinned_alloc(max(n, 1), C.byref(self._p)))
+        self.a = np.frombuffer((C.c_char * max(n, 1)).from_address(self._p.value), dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None) and lib is not None:
+            self.a = None
+            lib().rmr_pinned_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+
+class UploadRing:
+    """rmr_upload_*: `slots` device buffers filled on a copy stream of their own, so the inputs of step i + 1 travel
+    while step i computes (the reference uploads inside its cycle, detector.cu:388-399).
+        ring = UploadRing(2, bytes_per_slot)
+        dev = ring.begin(slot, [images_block, clouds_block])   # numpy arrays (ideally PinnedArray.a); returns at once
+        ring.wait(slot)                                        # before the step that reads the slot
+    begin() returns one DeviceArray per block, shaped like the block."""
+
+    def __init__(self, slots, bytes_per_slot, device=0):
+        self._h = C.c_void_p()
+        self.slots = slots
+        check(lib().rmr_upload_create(device, slots, int(bytes_per_slot), C.byref(self._h)))
+        self._keep = [None] * slots
+
+    def begin(self, slot, blocks):
+        n = len(blocks)
+        arrs = [b if (b.flags.c_contiguous) else np.ascontiguousarray(b) for b in blocks]
+        src = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        nb = (C.c_size_t * n)(*[a.nbytes for a in arrs])
+        out = (C.c_void_p * n)()
+        check(lib().rmr_upload_begin(self._h, slot, src, nb, n, out))
+        self._keep[slot] = arrs   # the sources must stay alive until the copies have landed
+        return [DeviceArray(out[i], a.shape, a.dtype) for i, a in enumerate(arrs)]
+
+    def wait(self, slot):
+        check(lib().rmr_upload_wait(self._h, slot))
+        self._keep[slot] = None
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib().rmr_upload_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
 
 # ------------------------------------------------------------------------------- whole path
 

@@ -158,6 +158,12 @@ SYMBOLS = {
     "rmr_robot_detector_detect": (C.c_int, [_vp, _P(Image), _P(Robot), _ip, C.c_int]),
     "rmr_robot_detector_detect_batch": (C.c_int, [_vp, _P(Image), C.c_int, _ip, C.c_int,
                                                   _P(Robot), _ip, C.c_int]),
+    "rmr_pinned_alloc": (C.c_int, [C.c_size_t, _P(_vp)]),
+    "rmr_pinned_free": (None, [_vp]),
+    "rmr_upload_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, _P(_vp)]),
+    "rmr_upload_destroy": (None, [_vp]),
+    "rmr_upload_begin": (C.c_int, [_vp, C.c_int, _P(_vp), _P(C.c_size_t), C.c_int, _P(_vp)]),
+    "rmr_upload_wait": (C.c_int, [_vp, C.c_int]),
     "rmr_robot_detector_read_heads": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _P(PreParam), _ip]),
     "rmr_robot_set_detection": (C.c_int, [_P(Robot), _P(Detection), _vp, C.c_int]),
     "rmr_compute_iou": (C.c_float, [_fp, _fp]),

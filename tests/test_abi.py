@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(built):
     assert declared == set(built.SYMBOLS), declared ^ set(built.SYMBOLS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.rmr_abi_version() == 5   # 5: rmr_robot_detector_read_heads; 4: rmr_locator_update_cluster_batch; 3: precision in the detector cfgs, 64-byte kernel names
+    assert L.rmr_abi_version() == 6   # 6: rmr_upload_* / rmr_pinned_*; 5: rmr_robot_detector_read_heads; 4: rmr_locator_update_cluster_batch; 3: precision in the detector cfgs, 64-byte kernel names
 
 
 def test_struct_layouts(built):
