@@ -61,6 +61,7 @@ class Locator {
 
    private:
     void update_into(const float* xyz, int n, int stride_bytes, int mem, float* diff_out);
+    void update_batch(const float* const* clouds, const int* n_points, int stride_bytes, int mem, int n_frames);
     void cluster_frames(const float* diff, int n_frames, int first_slot);
     float* image_ptr(int which);
     FrameSlot make_slot();
@@ -76,6 +77,10 @@ class Locator {
     DevBuf<unsigned long long> key_;  // per pixel (point index + 1) << 32 | depth bits
     DevBuf<float> bg_, diff_;
     DevBuf<float> diff_batch_;        // [max_frames][npx]: the foreground images of a batch (update_cluster_batch)
+    DevBuf<unsigned long long> key_batch_;  // [max_frames][npx]: per-frame key images of a batched update ...
+    DevBuf<int> fmax_batch_;                // ... and each frame's largest positive depth per pixel (float bits)
+    DevBuf<unsigned char> table_dev_;       // [max_frames] CloudTable
+    PinnedBuf<unsigned char> table_pin_;
     DevBuf<float> ring_;              // [queue_size][npx]
     int ring_len_ = 0, ring_head_ = 0;  // oldest slot, number of valid slots
     DevBuf<float> cloud_;             // staging for host clouds
@@ -83,8 +88,8 @@ class Locator {
 
     // cluster() scratch
     DevBuf<int> blk_count_, blk_offset_;
-    DevBuf<int> parent_, csize_, vroot_, vsize_, root_id_, counters_;   // counters_: [max_frames][4] + the overflow flag
-    int* overflow_ = nullptr;
+    DevBuf<int> parent_, csize_, vroot_, vsize_, root_id_, counters_;   // counters_: [max_frames][4]
+    DevBuf<int> slot_over_;   // [1 + max_frames]: foreground-capacity overflow of the current frame / of kept frame f
     DevBuf<float> fg_depth_;  // camera depth of each foreground point (prunes the pair tests of cluster())
     DevBuf<int> store_int_;
     DevBuf<float> store_f_;

@@ -138,6 +138,95 @@ __global__ __launch_bounds__(256) void loc_diff(LocParams P, RingOrder order,
     diff[p] = out;
 }
 
+// ---- update() of a batch of consecutive frames -------------------------------------------------
+// The updates of a stream are ordered (the background is a running max, the ring is the stream's history), but the
+// order only matters PER PIXEL.  So a batch needs two launches instead of two per frame:
+//   loc_scatter_batch  every point of every frame at once, into per-frame images: key[f] (the u64 "highest point index
+//                      wins" key of loc_scatter) and fmax[f] (the frame's largest positive depth per pixel, which is
+//                      what the frame contributes to the running-max background);
+//   loc_walk_batch     one thread per pixel walks the frames in order with the background and the ring of the last Q
+//                      depths in registers: exactly the sequence loc_scatter; loc_diff; loc_scatter; loc_diff ... sees
+//                      at that pixel, so the foreground images, the background and the ring are the same bits.
+struct CloudTable {
+    const char* xyz;   // device address of the frame's points (nullptr / n == 0: locate.cpp:160-171, nothing queued)
+    int n;
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void loc_scatter_batch(LocParams P, const CloudTable* __restrict__ clouds, int stride_bytes,
+                                                         unsigned long long* __restrict__ key, int* __restrict__ fmax, size_t npx) {
+    const CloudTable c = clouds[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n) return;
+    const float* pt = (const float*)(c.xyz + (size_t)i * stride_bytes);
+    const float p[3] = {pt[0], pt[1], pt[2]};
+    if (p[0] == 0 && p[1] == 0 && p[2] == 0) return;  // locate.cpp:176
+    if (p[0] > P.max_distance) return;                // locate.cpp:179
+    float uvd[3];
+    lidar_to_camera(P, p, uvd);
+    const float u = uvd[0], v = uvd[1], d = uvd[2];
+    if (!(u >= 0 && u < (float)P.wz && v >= 0 && v < (float)P.hz)) return;
+    const size_t idx = (size_t)blockIdx.y * npx + (size_t)(int)v * P.wz + (int)u;
+    if (d > 0) atomicMax(&fmax[idx], __float_as_int(d));
+    const unsigned long long k = ((unsigned long long)(unsigned)(i + 1) << 32) | (unsigned)__float_as_uint(d);
+    atomicMax(&key[idx], k);
+}
+
+// ring_in: the stream's ring before the batch, oldest first at slots (head + q) % Q; after the batch the ring is stored
+// oldest first from slot 0 (the host sets head = 0).  len0: images in the ring before the batch.
+template <int Q>
+__global__ __launch_bounds__(256) void loc_walk_batch(LocParams P, const CloudTable* __restrict__ clouds, int n_frames,
+                                                      unsigned long long* __restrict__ key, int* __restrict__ fmax,
+                                                      float* __restrict__ bg, float* __restrict__ ring, int head, int len0,
+                                                      float* __restrict__ diff, size_t npx) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npx) return;
+    float r[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) r[q] = q < len0 ? ring[(size_t)((head + q) % Q) * npx + p] : 0.0f;
+    float b = bg[p];
+    int len = len0;
+    for (int f = 0; f < n_frames; ++f) {
+        const size_t at = (size_t)f * npx + p;
+        if (clouds[f].n <= 0 || !clouds[f].xyz) {   // locate.cpp:160-171: foreground cleared, nothing queued
+            diff[at] = 0.0f;
+            continue;
+        }
+        const unsigned long long k = key[at];
+        const int m = fmax[at];
+        const float cur = k ? __uint_as_float((unsigned)(k & 0xffffffffull)) : 0.0f;
+        if (k) key[at] = 0;
+        if (m) {
+            fmax[at] = 0;
+            b = fmaxf(b, __int_as_float(m));   // both >= +0: the int atomicMax of loc_scatter on the background itself
+        }
+        if (len < Q) {   // uniform: push_back ...
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (q == len) r[q] = cur;
+            ++len;
+        } else {         // ... pop_front when over queue_size (locate.cpp:195-198)
+#pragma unroll
+            for (int q = 0; q + 1 < Q; ++q) r[q] = r[q + 1];
+            r[Q - 1] = cur;
+        }
+        float out = 0.0f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float value = r[q];
+            if (q < len && value != 0) {
+                const float df = b - value;
+                if (df >= P.min_diff && df <= P.max_diff) out = value;
+            }
+        }
+        diff[at] = out;
+    }
+    bg[p] = b;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        if (q < len) ring[(size_t)q * npx + p] = r[q];
+}
+
 // ---- cluster(): ordered compaction ---------------------------------------------------------
 
 constexpr int FG_PX_PER_BLOCK = 1024;  // 256 threads x 4 consecutive pixels
@@ -161,13 +250,13 @@ __global__ __launch_bounds__(256) void fg_count(const float* __restrict__ diff, 
     if (threadIdx.x == 0) blk_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// counters (per frame): [0] n_fg (clamped) [1] overflow flag [2] n_valid clusters.  overflow: what search() reports --
-// the current frame's flag, or (sticky: a batch of frames, cleared by the host before it) whether ANY frame overflowed
+// counters (per frame): [0] n_fg (clamped) [1] overflow flag [2] n_valid clusters.  slot_over[frame]: the overflow flag
+// kept with the frame's slot -- what search() of that frame reports (a batched search reports any of its frames')
 __global__ __launch_bounds__(1024) void fg_scan(const int* __restrict__ blk_count, int nblk,
                                                 int* __restrict__ blk_offset, int max_fg,
                                                 int* __restrict__ counters,
                                                 int* __restrict__ slot_n_fg, long slot_int_stride,
-                                                int* __restrict__ overflow, int sticky) {
+                                                int* __restrict__ slot_over) {
     __shared__ int wtot[16];
     __shared__ int carry;
     blk_count += (size_t)blockIdx.x * nblk;
@@ -202,11 +291,7 @@ __global__ __launch_bounds__(1024) void fg_scan(const int* __restrict__ blk_coun
         counters[0] = n > max_fg ? max_fg : n;
         counters[2] = 0;
         *slot_n_fg = counters[0];
-        if (sticky) {
-            if (n > max_fg) atomicMax(overflow, 1);
-        } else {
-            *overflow = n > max_fg ? 1 : 0;
-        }
+        slot_over[blockIdx.x] = counters[1];
     }
 }
 
@@ -506,12 +591,14 @@ __global__ __launch_bounds__(256) void slot_copy(const int* __restrict__ s_nfg,
                                                  const int* __restrict__ s_cl,
                                                  int* __restrict__ d_nfg, int* __restrict__ d_ncl,
                                                  int* __restrict__ d_pix, float* __restrict__ d_xyz,
-                                                 int* __restrict__ d_cl) {
+                                                 int* __restrict__ d_cl, const int* __restrict__ s_over,
+                                                 int* __restrict__ d_over) {
     const int n = *s_nfg;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) {
         *d_nfg = n;
         *d_ncl = *s_ncl;
+        *d_over = *s_over;
     }
     if (i >= n) return;
     d_pix[i] = s_pix[i];
@@ -765,9 +852,10 @@ Locator::Locator(const rmr_locator_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg.de
     vroot_.alloc(forest);
     vsize_.alloc(forest);
     root_id_.alloc(forest);
-    counters_.alloc(4 * bf + 1);
-    RMR_HIP(hipMemsetAsync(counters_.p, 0, (4 * bf + 1) * sizeof(int), stream_));
-    overflow_ = counters_.p + 4 * bf;
+    counters_.alloc(4 * bf);
+    RMR_HIP(hipMemsetAsync(counters_.p, 0, 4 * bf * sizeof(int), stream_));
+    slot_over_.alloc(1 + bf);   // [0] the current frame, [1 + f] kept frame f
+    RMR_HIP(hipMemsetAsync(slot_over_.p, 0, (1 + bf) * sizeof(int), stream_));
 
     const int nslots = 1 + cfg_.max_frames;
     slot_ints_.alloc((size_t)nslots * (2 + 2 * (size_t)mf));
@@ -890,10 +978,8 @@ void Locator::cluster_frames(const float* diff, int n_frames, int first_slot) {
     const long sis = 2 + 2 * (long)mf, sfs = 3 * (long)mf;   // ints / floats from one FrameSlot to the next
     FrameSlot& cur = slots_[first_slot];
     ProfScope ps(ctx_.prof, stream_, "loc_cluster", 0, (double)npx_ * 8 * n_frames);
-    const int sticky = n_frames > 1;
-    if (sticky) RMR_HIP(hipMemsetAsync(overflow_, 0, sizeof(int), stream_));
     fg_count<<<dim3(nblk, F), 256, 0, stream_>>>(diff, npx_, blk_count_.p);
-    fg_scan<<<F, 1024, 0, stream_>>>(blk_count_.p, nblk, blk_offset_.p, mf, counters_.p, cur.n_fg, sis, overflow_, sticky);
+    fg_scan<<<F, 1024, 0, stream_>>>(blk_count_.p, nblk, blk_offset_.p, mf, counters_.p, cur.n_fg, sis, slot_over_.p + first_slot);
     fg_compact<<<dim3(nblk, F), 256, 0, stream_>>>(prm_, diff, npx_, blk_offset_.p, mf, cur.fg_pixel, cur.fg_xyz, fg_depth_.p, sis, sfs);
     static std::once_flag once;
     std::call_once(once, [] {
@@ -933,15 +1019,94 @@ void Locator::update_cluster_batch(const float* const* clouds, const int* n_poin
     if (n_frames > cfg_.max_frames)
         fail(RMR_ERR_INVALID_ARGUMENT, "Locator: a batch of %d frames exceeds max_frames=%d", n_frames, cfg_.max_frames);
     if (diff_batch_.n < (size_t)n_frames * npx_) diff_batch_.alloc((size_t)cfg_.max_frames * npx_);
-    for (int f = 0; f < n_frames; ++f) update_into(clouds[f], n_points[f], stride_bytes, mem, diff_batch_.p + (size_t)f * npx_);
+    static const bool per_frame = std::getenv("RMR_LOC_BATCH_UPDATE") && std::atoi(std::getenv("RMR_LOC_BATCH_UPDATE")) == 0;
+    if (per_frame || n_frames == 1 || cfg_.queue_size > 8) {
+        for (int f = 0; f < n_frames; ++f) update_into(clouds[f], n_points[f], stride_bytes, mem, diff_batch_.p + (size_t)f * npx_);
+    } else {
+        update_batch(clouds, n_points, stride_bytes, mem, n_frames);
+    }
     cluster_frames(diff_batch_.p, n_frames, 1);
     // "the current frame" (read_image, foreground(), search(slot -1)) is the batch's last one
     RMR_HIP(hipMemcpyAsync(diff_.p, diff_batch_.p + (size_t)(n_frames - 1) * npx_, npx_ * sizeof(float), hipMemcpyDeviceToDevice, stream_));
     const FrameSlot& s = slots_[n_frames];
     const FrameSlot& d = slots_[0];
     slot_copy<<<(cfg_.max_foreground + 255) / 256, 256, 0, stream_>>>(
-        s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz, s.fg_cluster, d.n_fg, d.n_clusters, d.fg_pixel, d.fg_xyz, d.fg_cluster);
+        s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz, s.fg_cluster, d.n_fg, d.n_clusters, d.fg_pixel, d.fg_xyz, d.fg_cluster,
+        slot_over_.p + n_frames, slot_over_.p);
     RMR_HIP(hipGetLastError());
+}
+
+// The update stage of a batch as two launches (loc_scatter_batch, loc_walk_batch) instead of two per frame.
+void Locator::update_batch(const float* const* clouds, const int* n_points, int stride_bytes, int mem, int n_frames) {
+    if (stride_bytes < 12 || (stride_bytes & 3))
+        fail(RMR_ERR_INVALID_ARGUMENT, "Locator::update: stride_bytes must be a multiple of 4, >= 12");
+    const size_t F = (size_t)cfg_.max_frames;
+    if (key_batch_.n < F * npx_) {
+        key_batch_.alloc(F * npx_);
+        fmax_batch_.alloc(F * npx_);
+        RMR_HIP(hipMemsetAsync(key_batch_.p, 0, key_batch_.n * sizeof(unsigned long long), stream_));
+        RMR_HIP(hipMemsetAsync(fmax_batch_.p, 0, fmax_batch_.n * sizeof(int), stream_));
+        table_dev_.alloc(F * sizeof(CloudTable));
+        table_pin_.alloc(F * sizeof(CloudTable));
+    }
+    // the pinned table (and the pinned cloud block) are reused from batch to batch: the previous batch's copies must be done
+    RMR_HIP(hipStreamSynchronize(stream_));
+    CloudTable* tab = (CloudTable*)table_pin_.p;
+    int max_n = 0;
+    size_t host_bytes = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        const int n = clouds[f] && n_points[f] > 0 ? n_points[f] : 0;
+        if (n > cfg_.max_points) fail(RMR_ERR_CAPACITY, "Locator::update: %d points exceed max_points=%d", n, cfg_.max_points);
+        max_n = std::max(max_n, n);
+        tab[f].n = n;
+        tab[f].pad = 0;
+        tab[f].xyz = n ? (const char*)clouds[f] : nullptr;
+        if (n && mem != RMR_MEM_DEVICE) host_bytes += ((size_t)n * stride_bytes + 255) & ~(size_t)255;
+    }
+    if (host_bytes) {   // host clouds: one pinned block, one copy for the batch
+        if (host_bytes > cloud_.n * sizeof(float)) {
+            cloud_.alloc(host_bytes / 4 + 64);
+            cloud_pin_.alloc(host_bytes / 4 + 64);
+        }
+        size_t off = 0;
+        for (int f = 0; f < n_frames; ++f) {
+            if (!tab[f].n) continue;
+            const size_t bytes = (size_t)tab[f].n * stride_bytes;
+            std::memcpy((char*)cloud_pin_.p + off, clouds[f], bytes);
+            tab[f].xyz = (const char*)cloud_.p + off;
+            off += (bytes + 255) & ~(size_t)255;
+        }
+        RMR_HIP(hipMemcpyAsync(cloud_.p, cloud_pin_.p, off, hipMemcpyHostToDevice, stream_));
+    }
+    RMR_HIP(hipMemcpyAsync(table_dev_.p, table_pin_.p, (size_t)n_frames * sizeof(CloudTable), hipMemcpyHostToDevice, stream_));
+    const CloudTable* dtab = (const CloudTable*)table_dev_.p;
+    if (max_n > 0) {
+        ProfScope ps(ctx_.prof, stream_, "loc_scatter", 0, 0);
+        loc_scatter_batch<<<dim3((max_n + 255) / 256, n_frames), 256, 0, stream_>>>(prm_, dtab, stride_bytes, key_batch_.p, fmax_batch_.p, npx_);
+        RMR_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps(ctx_.prof, stream_, "loc_diff", 0, (double)npx_ * n_frames * 16);
+        const unsigned g = (unsigned)((npx_ + 255) / 256);
+#define RMR_WALK(QQ) loc_walk_batch<QQ><<<g, 256, 0, stream_>>>(prm_, dtab, n_frames, key_batch_.p, fmax_batch_.p, bg_.p, ring_.p, ring_head_, ring_len_, diff_batch_.p, npx_)
+        switch (cfg_.queue_size) {
+            case 1: RMR_WALK(1); break;
+            case 2: RMR_WALK(2); break;
+            case 3: RMR_WALK(3); break;
+            case 4: RMR_WALK(4); break;
+            case 5: RMR_WALK(5); break;
+            case 6: RMR_WALK(6); break;
+            case 7: RMR_WALK(7); break;
+            default: RMR_WALK(8); break;
+        }
+#undef RMR_WALK
+        RMR_HIP(hipGetLastError());
+    }
+    // the ring now lies oldest first from slot 0
+    int valid = 0;
+    for (int f = 0; f < n_frames; ++f) valid += tab[f].n > 0;
+    ring_len_ = std::min(cfg_.queue_size, ring_len_ + valid);
+    ring_head_ = 0;
 }
 
 void Locator::keep(int frame) {
@@ -951,7 +1116,8 @@ void Locator::keep(int frame) {
     const FrameSlot& s = slots_[0];
     const FrameSlot& d = slots_[1 + frame];
     slot_copy<<<(cfg_.max_foreground + 255) / 256, 256, 0, stream_>>>(
-        s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz, s.fg_cluster, d.n_fg, d.n_clusters, d.fg_pixel, d.fg_xyz, d.fg_cluster);
+        s.n_fg, s.n_clusters, s.fg_pixel, s.fg_xyz, s.fg_cluster, d.n_fg, d.n_clusters, d.fg_pixel, d.fg_xyz, d.fg_cluster,
+        slot_over_.p, slot_over_.p + 1 + frame);
     RMR_HIP(hipGetLastError());
 }
 
@@ -1003,7 +1169,7 @@ void Locator::search(rmr_robot* robots, int n, int slot) {
     }
     RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, stream_));
     int flags[2] = {0, 0};
-    RMR_HIP(hipMemcpyAsync(flags, overflow_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipMemcpyAsync(flags, slot_over_.p + slot + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));  // this frame's flag
     RMR_HIP(hipStreamSynchronize(stream_));
     for (int i = 0; i < n; ++i) {
         const float* o = loc_pin_.p + 4 * i;
@@ -1043,7 +1209,7 @@ void Locator::search_batch_begin(const rmr_robot* robots, const int* counts, int
     loc_pin_.ensure((size_t)4 * total);
     rects_dev_.ensure((size_t)5 * total);
     loc_dev_.ensure((size_t)4 * total);
-    search_flags_.ensure(2);
+    search_flags_.ensure((size_t)n_frames);
     int at = 0;
     for (int f = 0; f < n_frames; ++f)
         for (int i = 0; i < counts[f]; ++i, ++at) {
@@ -1065,8 +1231,7 @@ void Locator::search_batch_begin(const rmr_robot* robots, const int* counts, int
         RMR_HIP(hipGetLastError());
     }
     RMR_HIP(hipMemcpyAsync(loc_pin_.p, loc_dev_.p, sizeof(float) * 4 * total, hipMemcpyDeviceToHost, stream_));
-    search_flags_.p[0] = 0;
-    RMR_HIP(hipMemcpyAsync(search_flags_.p, overflow_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    RMR_HIP(hipMemcpyAsync(search_flags_.p, slot_over_.p + 1, sizeof(int) * n_frames, hipMemcpyDeviceToHost, stream_));
 }
 
 void Locator::search_batch_end(rmr_robot* robots, const int* counts, int n_frames, int cap) {
@@ -1085,7 +1250,9 @@ void Locator::search_batch_end(rmr_robot* robots, const int* counts, int n_frame
                 r.location[0] = o[1], r.location[1] = o[2], r.location[2] = o[3];
             }
         }
-    if (search_flags_.p[0]) fail(RMR_ERR_CAPACITY, "Locator: foreground exceeded max_foreground=%d points", cfg_.max_foreground);
+    for (int f = 0; f < n_frames; ++f)
+        if (search_flags_.p[f])
+            fail(RMR_ERR_CAPACITY, "Locator: foreground exceeded max_foreground=%d points (frame %d of the batch)", cfg_.max_foreground, f);
 }
 
 float* Locator::image_ptr(int which) {

@@ -349,8 +349,8 @@ def test_update_cluster_batch_equals_per_frame_calls(rmr, max_fg):
 
 
 def test_update_cluster_batch_reports_an_overflow_in_any_frame(rmr):
-    # the foreground of ONE frame inside a batch exceeds max_foreground: the batched search reports it (the per-frame
-    # calls would only see the flag of the last cluster())
+    # the foreground of ONE frame inside a batch exceeds max_foreground: the batched search reports it; a per-frame search
+    # reports the flag of the frame it searches (kept with the frame's slot)
     import ctypes as C
     from rm_radar_amd import _lib
     size, nf, cap = (640, 640), 4, 2
@@ -379,6 +379,13 @@ def test_update_cluster_batch_reports_an_overflow_in_any_frame(rmr):
         arr[f * cap].rect[:] = [float(v) for v in rect]
     with pytest.raises(rmr.CapacityError):
         loc.search_batch_raw(arr, np.ones(nf, np.int32), cap)
+    # ... while a search of ONE kept frame reports that frame's flag only, and the current frame is the batch's last
+    one = [rmr.Robot(rect=tuple(float(v) for v in rect))]
+    loc.search(one, frame=0)
+    with pytest.raises(rmr.CapacityError):
+        loc.search(one, frame=1)
+    loc.search(one, frame=2)
+    loc.search(one)
     loc.close()
     # the same stream without the dense frame: nothing overflows
     clouds[1] = clouds[0]
