@@ -191,6 +191,17 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             a.wt_t32 = dw32.p;
             a.wt_t32_bytes = (unsigned)(p32.size() * sizeof(__half));
         }
+        // conv_w1d (ids 980..): the Winograd F(2, 3) transformed weights
+        DevBuf<__half> dw1d;
+        if (tile >= 980 && tile < 1000 && kh == 3 && kw == 3 && cin_pad % 32 == 0) {
+            std::vector<__half> pw;
+            pack_conv_weights_w1d(packed.data(), cout_pad, cin_pad, a.Kp, pw);
+            dw1d.alloc(pw.size());
+            RMR_HIP(hipMemcpyAsync(dw1d.p, pw.data(), pw.size() * sizeof(__half), hipMemcpyHostToDevice, ctx.stream));
+            RMR_HIP(hipStreamSynchronize(ctx.stream));
+            a.wt_w1d = dw1d.p;
+            a.wt_w1d_bytes = (unsigned)(pw.size() * sizeof(__half));
+        }
         // conv_t32f8 (ids 900..): e4m3 weights with one scale per output channel, the input quantised on the device
         DevBuf<unsigned char> dw8, dx8;
         DevBuf<float> dws;
@@ -220,10 +231,15 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             RMR_HIP(hipMemsetAsync(dtiming.p, 0, 64, ctx.stream));
             a.timing = dtiming.p;
         }
-        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..799: conv_pw variant; 800..899: conv_t32 tile; 900..949: conv_t32f8 tile; 950..999: conv_g32 tile
+        // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..799: conv_pw variant; 800..899: conv_t32 tile; 900..949: conv_t32f8 tile; 950..979: conv_g32 tile; 980..999: conv_w1d tile
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
-        } else if (tile >= 950 && tile < 1000) {
+        } else if (tile >= 980 && tile < 1000) {
+            const int t = tile - 980;
+            if (t >= conv_w1d_num_tiles() || !conv_w1d_supported(a, t))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: w1d tile %d cannot run this layer", t);
+            launch_conv_w1d(ctx, ctx.stream, a, t);
+        } else if (tile >= 950 && tile < 980) {
             const int t = tile - 950;
             if (t >= conv_g32_num_tiles() || !conv_g32_supported(a, t))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: g32 tile %d cannot run this layer", t);
@@ -391,6 +407,15 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
             a.wt_t32 = dw32.p;
             a.wt_t32_bytes = (unsigned)(p32.size() * 2);
         }
+        DevBuf<__half> dw1d;
+        if (k == 3 && tile >= 980 && tile < 1000 && cin % 32 == 0) {
+            std::vector<__half> pw;
+            pack_conv_weights_w1d(hw.data(), cout, cin, a.Kp, pw);
+            dw1d.alloc(pw.size());
+            RMR_HIP(hipMemcpy(dw1d.p, pw.data(), pw.size() * 2, hipMemcpyHostToDevice));
+            a.wt_w1d = dw1d.p;
+            a.wt_w1d_bytes = (unsigned)(pw.size() * 2);
+        }
         DevBuf<unsigned char> dw8, dx8;
         DevBuf<float> dws;
         if (k == 3 && tile >= 900 && tile < 950) {
@@ -432,7 +457,11 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         a.in_bytes = (unsigned)(n * img_in * 2);
         a.wt_bytes = (unsigned)(hw.size() * 2);
         const auto launch = [&] {
-            if (tile >= 950 && tile < 1000) {
+            if (tile >= 980 && tile < 1000) {
+                if (tile - 980 >= conv_w1d_num_tiles() || !conv_w1d_supported(a, tile - 980))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: w1d tile %d cannot run this layer", tile - 980);
+                launch_conv_w1d(ctx, ctx.stream, a, tile - 980);
+            } else if (tile >= 950 && tile < 980) {
                 if (tile - 950 >= conv_g32_num_tiles() || !conv_g32_supported(a, tile - 950))
                     fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: g32 tile %d cannot run this layer", tile - 950);
                 launch_conv_g32(ctx, ctx.stream, a, tile - 950);

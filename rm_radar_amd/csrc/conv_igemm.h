@@ -41,6 +41,10 @@ struct ConvArgs {
     // conv_t32 only: the same weights as the LDS images of their (chunk, tap) slices (pack_conv_weights_t32)
     const __half* wt_t32;
     unsigned wt_t32_bytes;
+    // conv_w1d only: the Winograd F(2, 3) transformed weights U = g G^T as the LDS images of their 12 (filter row, xi)
+    // slices per 32-channel chunk (pack_conv_weights_w1d)
+    const __half* wt_w1d;
+    unsigned wt_w1d_bytes;
     // conv_t32f8 only: the input quantised to e4m3 (rows of in8_cs bytes, zero beyond Cin), the weights as e4m3
     // LDS images with one scale per output channel (pack_conv_weights_t32f8)
     const unsigned char* in8;
@@ -132,6 +136,13 @@ int conv_g32_num_tiles();
 ConvTile conv_g32_tile(int id);
 bool conv_g32_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_g32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+// 3x3 / stride-1 layers through Winograd F(2, 3) along x on the conv_t32 skeleton (conv_w1d.hip): 1.5x fewer MFMAs, the
+// input transform in LDS, the transformed weights pre-packed (a.wt_w1d); even map widths, Cin % 32 == 0
+int conv_w1d_num_tiles();
+ConvTile conv_w1d_tile(int id);
+bool conv_w1d_supported(const ConvArgs& a, int tile);  // tile < 0: any
+void launch_conv_w1d(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+void pack_conv_weights_w1d(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out);
 // the fp8 form (conv_t32f8.hip): e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4, f16 output
 int conv_t32f8_num_tiles();
 ConvTile conv_t32f8_tile(int id);

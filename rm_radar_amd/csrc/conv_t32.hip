@@ -143,10 +143,14 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     // MFMA time of a K = 864 tile) runs under the other's K loop -- which only happens when they are out of
     // phase.  Launched together and walking equal tiles they would stay in lockstep for the whole launch, so the
     // workgroup in the CU's odd slot (HW_ID.TG_ID, the barrier resource it was given) starts half a tile late.
-    if (stagger > 0) {
+    // prio (RMR_T32_PRIO, default 1): 1 = the K loop runs at s_setprio 1 and the epilogue at 0 -- the other workgroup of the
+    // CU keeps the matrix pipe fed while this one does its SiLUs and stores (isolated: M1638400 N96 K864 346 -> 331 us,
+    // M409600 N192 K1728 282 -> 279; in the bench 1945-1947 -> 1952-1963 frames/s); 2 = the reverse (no gain); 0 = off
+    const int prio = stagger >> 16;
+    if ((stagger & 0xffff) > 0) {
         const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4);   // HW_REG_HW_ID[19:16] = TG_ID
         if (hw_id & 1)
-            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles each
+            for (int i = 0; i < (stagger & 0xffff); ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles each
     }
 
     const auto dma_in = [](u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
@@ -210,6 +214,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     unsigned w_live = 1u;
 
     for (;;) {
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        if (prio == 2) __builtin_amdgcn_s_setprio(0);
         // ---- this tile and the next one -------------------------------------------------------------
         const int vbn = vb + G;
         const bool has_next = vbn < n_tiles;
@@ -376,6 +382,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
         }
 
         // ---- epilogue; the next tile's first slices and input range are in flight meanwhile
+        if (prio == 1) __builtin_amdgcn_s_setprio(0);
+        if (prio == 2) __builtin_amdgcn_s_setprio(1);
         if constexpr (ABL & 2) {
 #pragma unroll
             for (int i = 0; i < MREP; ++i)
@@ -515,7 +523,8 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     static const int stagger_env = std::getenv("RMR_T32_STAGGER") ? std::atoi(std::getenv("RMR_T32_STAGGER")) : -1;
     const int taps = a.Cin / 32 * 9;
     const int stagger = t.wgs_per_cu < 2 || grid <= ctx.num_cus ? 0 : stagger_env >= 0 ? stagger_env : (taps * 500 + 4095) / 4096;
-    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, stagger);
+    static const int prio_env = std::getenv("RMR_T32_PRIO") ? std::atoi(std::getenv("RMR_T32_PRIO")) : 1;
+    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, stagger | (prio_env << 16));
     RMR_HIP(hipGetLastError());
 }
 

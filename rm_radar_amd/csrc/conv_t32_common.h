@@ -66,14 +66,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 // where it is used (lgkmcnt, no registers held); otherwise the wave's values are fetched into registers up front.
 // SCALE (the fp8 kernel; needs BIAS_LDS): the accumulators are multiplied by one scale per output channel before the
 // bias is added; the scales are Cout_pad floats in LDS right behind the bias vector.
-template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE, bool SCALE = false, int AUX = 0>
+// RS / row_off (conv_w1d): fragment row r of the tile is pixel RS * r + row_off (RS = 2: the rows are 2-pixel Winograd tiles and
+// the call stores their even or odd pixels); EPI = 0 only.
+template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE, bool SCALE = false, int AUX = 0, int RS = 1>
 __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int bias_off,
-                                              int m0, int n0, int wm, int wn, int lane) {
+                                              int m0, int n0, int wm, int wn, int lane, int row_off = 0) {
+    static_assert(RS == 1 || EPI == 0, "strided rows leave through the lane-pair stores");
     static_assert(!SCALE || BIAS_LDS, "scales live in LDS");
     constexpr int STG_PITCH = NREP * 64 + 16;   // bytes per pixel row of the epilogue stage
     const int fr = lane & 31, kq = lane >> 5;
     const int cq = kq * 4;
-    const int mw0 = __builtin_amdgcn_readfirstlane(m0 + wm * MREP * 32);   // the wave's first pixel row
+    const int mw0 = __builtin_amdgcn_readfirstlane(RS * (m0 + wm * MREP * 32) + row_off);   // the wave's first pixel row
     const int nw0 = __builtin_amdgcn_readfirstlane(n0 + wn * NREP * 32);   // and first output channel
     const long rows_left = (long)a.M - mw0;
     const auto view_bytes = [&](int cs) {
@@ -82,7 +85,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
     };
     const __amdgpu_buffer_rsrc_t out_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)((_Float16*)a.out + (long)mw0 * a.out_cs), 0, view_bytes(a.out_cs), 0x00020000);
-    const unsigned out_lane = (unsigned)(fr * a.out_cs + a.out_co + nw0 + kq * 8) * 2u;   // fragment row 0, channel group 0
+    const unsigned out_lane = (unsigned)(RS * fr * a.out_cs + a.out_co + nw0 + kq * 8) * 2u;   // fragment row 0, channel group 0
     // ---- every load of the epilogue, ahead of its first store ------------------------------------------------
     float4 bias[BIAS_LDS ? 1 : NREP][BIAS_LDS ? 1 : 4];
     if constexpr (!BIAS_LDS) {
@@ -96,14 +99,14 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
     if constexpr (RES) {
         const __amdgpu_buffer_rsrc_t res_rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)a.res + (long)mw0 * a.res_cs), 0, view_bytes(a.res_cs), 0x00020000);
-        const unsigned res_lane = (unsigned)(fr * a.res_cs + a.res_co + nw0 + kq * 8) * 2u;
+        const unsigned res_lane = (unsigned)(RS * fr * a.res_cs + a.res_co + nw0 + kq * 8) * 2u;
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
 #pragma unroll
             for (int j = 0; j < NREP; ++j)
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp)
-                    rres[i][j][gp] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_lane + (unsigned)(i * 32 * a.res_cs + j * 32 + gp * 16) * 2u, 0, 0);
+                    rres[i][j][gp] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_lane + (unsigned)(RS * i * 32 * a.res_cs + j * 32 + gp * 16) * 2u, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
@@ -176,7 +179,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
                     if constexpr (NOSTORE)
                         asm volatile("" : : "v"(o.u));
                     else
-                        __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(i * 32 * a.out_cs + j * 32 + gp * 16) * 2u, 0, AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(RS * i * 32 * a.out_cs + j * 32 + gp * 16) * 2u, 0, AUX);
                 } else {
                     *(u32x4*)(smem + stg_base + fr * STG_PITCH + (j * 32 + gp * 16 + kq * 8) * 2) = o.u;
                 }
@@ -201,9 +204,9 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
 // bias_off: LDS offset of the bias vector (BIAS_LDS kernels); CAN_RES = false: the kernel's layers do not carry a
 // shortcut in the network (1x1 and strided layers, the 256-channel head tiles), so the wide shortcut path and its
 // registers are not compiled in -- a shortcut still works, through the 8-byte path below
-template <int MREP, int NREP, int EPI, bool BIAS_LDS, bool CAN_RES, bool NOSTORE = false, int AUX = 0>
+template <int MREP, int NREP, int EPI, bool BIAS_LDS, bool CAN_RES, bool NOSTORE = false, int AUX = 0, int RS = 1>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int bias_off,
-                                         int m0, int n0, int wm, int wn, int lane) {
+                                         int m0, int n0, int wm, int wn, int lane, int row_off = 0) {
     const int fr = lane & 31, kq = lane >> 5;
     const int cq = kq * 4;
     // 16-byte stores need 8-channel alignment
@@ -211,17 +214,17 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP
     if (wide) {
         if constexpr (CAN_RES) {
             if (a.res) {
-                epilogue_wide<MREP, NREP, EPI, true, BIAS_LDS, NOSTORE, false, AUX>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+                epilogue_wide<MREP, NREP, EPI, true, BIAS_LDS, NOSTORE, false, AUX, RS>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane, row_off);
                 return;
             }
         }
-        epilogue_wide<MREP, NREP, EPI, false, BIAS_LDS, NOSTORE, false, AUX>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+        epilogue_wide<MREP, NREP, EPI, false, BIAS_LDS, NOSTORE, false, AUX, RS>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane, row_off);
         return;
     }
     // everything else (f32 output, no activation, 4-channel aligned views): 8-byte pieces, loads as they come
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
-        const int m = m0 + (wm * MREP + i) * 32 + fr;
+        const int m = RS * (m0 + (wm * MREP + i) * 32 + fr) + row_off;
         if (m >= a.M) continue;
 #pragma unroll
         for (int j = 0; j < NREP; ++j)

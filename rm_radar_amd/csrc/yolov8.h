@@ -70,6 +70,7 @@ class Yolov8 {
     struct ConvW {
         DevBuf<__half> w;
         DevBuf<__half> w32;  // 3x3 layers with Cin % 32 == 0: the LDS images conv_t32 streams (pack_conv_weights_t32)
+        DevBuf<__half> w1d;  // 3x3 layers with Cin % 32 == 0: the Winograd F(2, 3) transformed weights conv_w1d streams
         DevBuf<float> b;
         DevBuf<unsigned char> w8;  // fp8 plan: e4m3 LDS images (pack_conv_weights_t32f8) ...
         DevBuf<float> wscale;      // ... and the scale of every output channel

@@ -162,6 +162,15 @@ void Yolov8::upload_t32(ConvW& cw, const std::vector<__half>& packed) {
     pack_conv_weights_t32(packed.data(), cw.cout_pad, cw.cin, cw.Kp, p32, cw.k * cw.k);
     cw.w32.alloc(p32.size());
     RMR_HIP(hipMemcpy(cw.w32.p, p32.data(), p32.size() * sizeof(__half), hipMemcpyHostToDevice));
+    // the Winograd F(2, 3) form of a 3x3 layer (conv_w1d): a measured experiment, slower than conv_t32 on every layer
+    // (conv_w1d.hip), so only offered to the tuner with RMR_WINOGRAD=1
+    const bool wino = std::getenv("RMR_WINOGRAD") && std::atoi(std::getenv("RMR_WINOGRAD")) != 0;   // read per detector
+    if (wino && cw.k == 3) {
+        std::vector<__half> pw;
+        pack_conv_weights_w1d(packed.data(), cw.cout_pad, cw.cin, cw.Kp, pw);
+        cw.w1d.alloc(pw.size());
+        RMR_HIP(hipMemcpy(cw.w1d.p, pw.data(), pw.size() * sizeof(__half), hipMemcpyHostToDevice));
+    }
 }
 
 // two convs over the same input, concatenated along Cout (Detect cv2.i.0 + cv3.i.0)
@@ -647,7 +656,9 @@ void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     const int split = choice / 1000, c = choice % 1000;
     if ((a.in_slab_c || a.out_slab_c) && (c < 700 || c >= 800 || split))
         fail(RMR_ERR_LOGIC, "kernel %d cannot address planar channel groups", choice);
-    if (c >= 950) {
+    if (c >= 980) {
+        launch_conv_w1d(ctx_, s, a, c - 980);
+    } else if (c >= 950) {
         launch_conv_g32(ctx_, s, a, c - 950);
     } else if (c >= 900) {
         launch_conv_t32f8(ctx_, s, a, c - 900);
@@ -700,6 +711,10 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
     if (conv_t32_supported(a, -1))
         for (int t = 0; t < conv_t32_num_tiles(); ++t)
             if (conv_t32_supported(a, t)) cands.push_back(800 + t);
+    // the same layers through Winograd F(2, 3) along x (1.5x fewer MFMAs; chip-filling launches only: a tile is 512 pixels)
+    if (conv_w1d_supported(a, -1) && (a.M >= 256 * ctx_.num_cus || std::getenv("RMR_TUNE_ONLY")))
+        for (int t = 0; t < conv_w1d_num_tiles(); ++t)
+            if (conv_w1d_supported(a, t)) cands.push_back(980 + t);
     // 1x1 and strided 3x3 layers on the same skeleton (a chip-filling number of 256-pixel tiles only, unless a test
     // pins the family)
     if (conv_g32_supported(a, -1) && !conv_t32_supported(a, -1) && (a.M >= 128 * ctx_.num_cus || std::getenv("RMR_TUNE_ONLY")))
@@ -833,6 +848,7 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
                conv_dma_splitk_ws_floats(a, c - 100, split) <= kSplitKWsFloats;
     }
     if (a.in8) return !split && c >= 900 && c - 900 < conv_t32f8_num_tiles() && conv_t32f8_supported(a, c - 900);
+    if (c >= 980) return c - 980 < conv_w1d_num_tiles() && conv_w1d_supported(a, c - 980);
     if (c >= 950) return c - 950 < conv_g32_num_tiles() && conv_g32_supported(a, c - 950);
     if (c >= 900) return false;
     if (c >= 800) return c - 800 < conv_t32_num_tiles() && conv_t32_supported(a, c - 800);
@@ -848,8 +864,8 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
 }
 
 // header: "rmr-tune <version> <ops> <w> <h> <plan signature> <CUs> <device name without blanks>"
-// (the version moves whenever the set of candidate kernels does: 11 = conv_g32 added)
-static constexpr int kTuneFileVersion = 11;
+// (the version moves whenever the set of candidate kernels does: 11 = conv_g32 added, 12 = conv_w1d)
+static constexpr int kTuneFileVersion = 12;
 static std::string device_tag(int device) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return "unknown";
@@ -956,6 +972,10 @@ ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
     if (cw.w32.p) {
         a.wt_t32 = cw.w32.p;
         a.wt_t32_bytes = (unsigned)(cw.w32.n * sizeof(__half));
+    }
+    if (cw.w1d.p) {
+        a.wt_w1d = cw.w1d.p;
+        a.wt_w1d_bytes = (unsigned)(cw.w1d.n * sizeof(__half));
     }
     if (op.fp8) {
         const size_t q_bytes = (size_t)n * a.H * a.W * op.q_pitch;
