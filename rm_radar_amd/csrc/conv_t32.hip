@@ -65,6 +65,16 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     constexpr unsigned OOB = 0xffff0000u;
     static_assert(R >= 4 && R <= 6, "ring depth");
     static_assert((R - 3) * D <= 63, "vmcnt is 6 bits");
+    // (Round 3, measured and dropped: (i) the AccVGPR form of the MFMAs -- hipcc selects the ArchVGPR form for a kernel whose
+    // register budget is <= 256 unless the function names an AccVGPR; tools/microbench/mfma_issue.hip has the bare AccVGPR
+    // form 12 % / 8 % faster at one / two waves per SIMD on random operands -- forced with one `asm("" : "+a"(x))`: the
+    // budget splits 128 + 128, the epilogue pays v_accvgpr_read for every value and spills 16-48 registers, and the
+    // layers run 2-5 % SLOWER (288 vs 282, 358 vs 340, 148 vs 143 us).  (ii) A ping-pong form: the eight waves as two
+    // groups of four (waves w and w + 4 share a SIMD: tools/microbench/wave_simd.hip) that alternate a bare 12-MFMA
+    // segment with a filler segment (10 ds_read_b128, the DMA slots, the counted wait) between s_barriers, as the guide's
+    // 8-wave attention loop does: bit-exact, and 534 us against 282 on M409600 N192 K1728 -- its MFMA segments alone take
+    // 307 us, its filler segments alone 191, together 534: next to a wave that streams bare MFMAs the partner's
+    // vector-memory and LDS instructions do not get issued, so the segments add up instead of overlapping.)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
@@ -404,6 +414,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     }
     wait_vm<0>();
 }
+
 
 struct T32Tile {
     int bm, bn, threads, a_slots, ring, nrep, epi, wgs_per_cu;
