@@ -254,6 +254,22 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             if (t >= conv_t32_num_tiles() || !conv_t32_supported(a, t))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: t32 tile %d cannot run this layer", t);
             launch_conv_t32(ctx, ctx.stream, a, t);
+        } else if (tile >= 1000 && tile % 1000 >= 800 && tile % 1000 < 900) {
+            // 1000 * split + 800 + t32 tile: split-K conv_t32 through a private workspace
+            const int split = tile / 1000, t = tile % 1000 - 800;
+            if (t >= conv_t32_num_tiles() || !conv_t32_splitk_supported(a, t, split, ctx.num_cus))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: split-K t32 tile %d cannot run this layer", tile);
+            DevBuf<float> ws;
+            DevBuf<int> cnt;
+            ws.alloc(conv_t32_splitk_ws_floats(a, t, split));
+            cnt.alloc(conv_t32_splitk_tiles(a, t));
+            RMR_HIP(hipMemsetAsync(cnt.p, 0, cnt.n * sizeof(int), ctx.stream));
+            a.split = split;
+            a.splitk_ws = ws.p;
+            a.splitk_cnt = cnt.p;
+            launch_conv_t32(ctx, ctx.stream, a, t);
+            launch_conv_t32(ctx, ctx.stream, a, t);  // twice: the counters must re-arm themselves
+            RMR_HIP(hipStreamSynchronize(ctx.stream));
         } else if (tile >= 1000) {
             // 1000 * split + 100 + dma tile: split-K through a private workspace
             const int split = tile / 1000, t = tile % 1000 - 100;
@@ -456,8 +472,24 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         a.act = std::getenv("RMR_BENCH_ACT") ? std::atoi(std::getenv("RMR_BENCH_ACT")) : 1;
         a.in_bytes = (unsigned)(n * img_in * 2);
         a.wt_bytes = (unsigned)(hw.size() * 2);
+        // 1000 * split + 800 + t32 tile: split-K conv_t32
+        DevBuf<float> sk_ws;
+        DevBuf<int> sk_cnt;
+        if (tile >= 1000 && tile % 1000 >= 800 && tile % 1000 < 900) {
+            const int split = tile / 1000, t = tile % 1000 - 800;
+            if (t >= conv_t32_num_tiles() || !conv_t32_splitk_supported(a, t, split, ctx.num_cus))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: split-K t32 tile %d cannot run this layer", tile);
+            sk_ws.alloc(conv_t32_splitk_ws_floats(a, t, split));
+            sk_cnt.alloc(conv_t32_splitk_tiles(a, t));
+            RMR_HIP(hipMemsetAsync(sk_cnt.p, 0, sk_cnt.n * sizeof(int), ctx.stream));
+            a.split = split;
+            a.splitk_ws = sk_ws.p;
+            a.splitk_cnt = sk_cnt.p;
+        }
         const auto launch = [&] {
-            if (tile >= 980 && tile < 1000) {
+            if (tile >= 1000 && tile % 1000 >= 800 && tile % 1000 < 900) {
+                launch_conv_t32(ctx, ctx.stream, a, tile % 1000 - 800);
+            } else if (tile >= 980 && tile < 1000) {
                 if (tile - 980 >= conv_w1d_num_tiles() || !conv_w1d_supported(a, tile - 980))
                     fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: w1d tile %d cannot run this layer", tile - 980);
                 launch_conv_w1d(ctx, ctx.stream, a, tile - 980);

@@ -128,6 +128,10 @@ int conv_t32_num_tiles();
 ConvTile conv_t32_tile(int id);
 bool conv_t32_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
+// split-K (a.split > 1, small batches): one workgroup per (tile, range of 32-channel chunks), partial tiles through a.splitk_ws
+int conv_t32_splitk_tiles(const ConvArgs& a, int tile);
+size_t conv_t32_splitk_ws_floats(const ConvArgs& a, int tile, int split);
+bool conv_t32_splitk_supported(const ConvArgs& a, int tile, int split, int num_cus);
 // taps = KH * KW of the layer (9, or 1 for the 1x1 layers conv_g32 runs)
 void pack_conv_weights_t32(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out, int taps = 9);
 // 1x1 and 3x3 layers of any stride with Cin % 32 == 0 on the same skeleton (conv_g32.hip): the pixel rows of

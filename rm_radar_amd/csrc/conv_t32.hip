@@ -94,16 +94,24 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     const int nt_count = a.Cout_pad / BN;
     const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
     const int G = gridDim.x;  // a multiple of 8: vb & 7 is this workgroup's XCD for every tile it walks
+    // split-K (a.split > 1; small batches, where the tiles alone cannot fill the chip): `split` consecutive logical ids
+    // (same XCD) share one output tile, each accumulating a contiguous range of 32-channel chunks; the launch has one
+    // workgroup per (tile, split), so nobody walks on to a second tile
+    const int split = a.split > 1 ? a.split : 1;
+    int zsplit = 0, tile_id = 0;
     const auto tile_m0n0 = [&](int vb, int& m0, int& n0) {
         const int xcd = vb & 7;
         const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
-        m0 = (lid / nt_count) * BM;
-        n0 = (lid % nt_count) * BN;
+        tile_id = lid / split;
+        zsplit = lid - tile_id * split;
+        m0 = (tile_id / nt_count) * BM;
+        n0 = (tile_id % nt_count) * BN;
     };
     int vb = blockIdx.x;
     if (vb >= n_tiles) return;
     int m0, n0;
     tile_m0n0(vb, m0, n0);
+    const int my_tile = tile_id, my_z = zsplit;
     const int W = a.W;
     const int npix = a.M;        // stride 1: input and output pixels share the linear index
 
@@ -120,7 +128,9 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     const unsigned lane16 = (unsigned)lane * 16u;
     const int na = a_rows / 16;                                   // input-range DMA blocks per chunk
     const int chunks = a.Cin / 32;
-    const int total = chunks * 9;
+    const int cc_begin = chunks * my_z / split, cc_end = chunks * (my_z + 1) / split;   // this workgroup's chunks
+    const int g0 = cc_begin * 9;       // its first weight slice
+    const int total = cc_end * 9;      // one past its last
     const unsigned wstep = (unsigned)(a.Cout_pad / 16) * 1024u;   // bytes of one (chunk, tap) slice of all channels
     const unsigned scratch = sgpr(lds0 + zero_off);
 
@@ -172,12 +182,12 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     // ---- cold start: the whole input range of chunk 0, weight slices 0 .. R-2 of the first tile -----------
     {
         const int pl0 = m0 - W - 1 + lrow;
-        for (int ia = wave; ia < na; ia += NW) dma_in(in_rsrc, sgpr(lds0 + ia * 1024), in_off(pl0, ia, 0), 0u);
+        for (int ia = wave; ia < na; ia += NW) dma_in(in_rsrc, sgpr(lds0 + ia * 1024), in_off(pl0, ia, cc_begin), 0u);
 #pragma unroll
         for (int s = 0; s < R - 1; ++s)
             for (int q = wave; q < NB; q += NW)
-                dma16s(wt_rsrc, sgpr(lds0 + ring_base + s * SLOT_BYTES + q * 1024), s < total ? lane16 : OOB,
-                       sgpr((unsigned)s * wstep + (unsigned)(n0 / 16 + q) * 1024u));
+                dma16s(wt_rsrc, sgpr(lds0 + ring_base + s * SLOT_BYTES + q * 1024), g0 + s < total ? lane16 : OOB,
+                       sgpr((unsigned)(g0 + s) * wstep + (unsigned)(n0 / 16 + q) * 1024u));
     }
 
     // ---- fragment constants ------------------------------------------------------------------------
@@ -218,8 +228,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     int slot = 0;                     // ring slot of the tap being computed
     int abuf = 0;                     // input buffer of the chunk being computed
     // the weight stream: slice gw of the tile whose channel-tile offset is w_tile is the next one to fetch
-    unsigned gw = R - 1;
-    unsigned gwoff = (unsigned)(R - 1) * wstep;
+    unsigned gw = g0 + R - 1;
+    unsigned gwoff = (unsigned)(g0 + R - 1) * wstep;
     unsigned w_tile = (unsigned)(n0 / 16) * 1024u;
     unsigned w_live = 1u;
 
@@ -268,10 +278,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
             for (int j = 0; j < NREP; ++j) wa[j] = lds16(wcur + j * 2048);
         }
 
-        for (int cc = 0; cc < chunks; ++cc) {
+        for (int cc = cc_begin; cc < cc_end; ++cc) {
             const int abuf_next = a_buf_bytes - abuf;
             // the range fetched during this chunk: the next chunk of this tile, or chunk 0 of the next tile
-            const bool in_tile = cc + 1 < chunks;
+            const bool in_tile = cc + 1 < cc_end;
             const bool a_live = in_tile || has_next;
             const int a_pl = in_tile ? pl : pln;
             const int a_cc = in_tile ? cc + 1 : 0;
@@ -391,6 +401,56 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
             abuf = abuf_next;
         }
 
+        // ---- split-K: the partial tiles meet in the workspace; the last arriver sums ALL of them in split order (its own
+        // re-read from the workspace), so the result does not depend on who arrived last: run-to-run deterministic
+        if (split > 1) {
+            constexpr int TILE_F4 = NW * MREP * NREP * 64 * 4;  // float4 per partial tile
+            constexpr int SC = 17;                              // sc0 sc1: write-through stores, loads that bypass L1 and L2
+            int* const is_last = (int*)(smem + bias_off + a.Cout_pad * 4);
+            // The partial tiles travel as write-through (sc0 sc1) 16-byte stores and are read back with sc0 sc1 loads: no
+            // agent-scope release / acquire fence (an L2 write-back and an L1 invalidate: 5-13 us per seam on this chip, as
+            // much as the K loop of a batch-1 layer), only the wave's own vmcnt(0) before the ticket (guide, "publish-large")
+            const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((float4*)a.splitk_ws + (size_t)my_tile * split * TILE_F4), 0, (unsigned)((size_t)split * TILE_F4 * 16), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const u32x4 v = {__float_as_uint(acc[i][j][4 * r]), __float_as_uint(acc[i][j][4 * r + 1]), __float_as_uint(acc[i][j][4 * r + 2]),
+                                         __float_as_uint(acc[i][j][4 * r + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, ws_rsrc, (unsigned)((my_z * TILE_F4 + (((wave * MREP + i) * NREP + j) * 4 + r) * 64 + lane) * 16), 0, SC);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int ticket = __hip_atomic_fetch_add(a.splitk_cnt + my_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *is_last = ticket == split - 1;
+                if (ticket == split - 1) __hip_atomic_store(a.splitk_cnt + my_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+            }
+            __syncthreads();
+            if (!*is_last) return;
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int z = 0; z < split; ++z) {
+#pragma unroll
+                for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(ws_rsrc, (unsigned)((z * TILE_F4 + (((wave * MREP + i) * NREP + j) * 4 + r) * 64 + lane) * 16), 0, SC);
+                            acc[i][j][4 * r] += __uint_as_float(p[0]), acc[i][j][4 * r + 1] += __uint_as_float(p[1]);
+                            acc[i][j][4 * r + 2] += __uint_as_float(p[2]), acc[i][j][4 * r + 3] += __uint_as_float(p[3]);
+                        }
+            }
+        }
+
         // ---- epilogue; the next tile's first slices and input range are in flight meanwhile
         if (prio == 1) __builtin_amdgcn_s_setprio(0);
         if (prio == 2) __builtin_amdgcn_s_setprio(1);
@@ -483,7 +543,7 @@ constexpr int kNumT32Tiles = sizeof(kT32Tiles) / sizeof(kT32Tiles[0]);
 
 int t32_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
 int t32_lds_bytes(const T32Tile& t, int W, int cout_pad) {
-    return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + (t.epi ? (t.threads / 64) * 32 * (t.nrep * 64 + 16) : 0) + cout_pad * 4;
+    return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + (t.epi ? (t.threads / 64) * 32 * (t.nrep * 64 + 16) : 0) + cout_pad * 4 + 16;
 }
 
 }  // namespace
@@ -500,6 +560,21 @@ bool conv_t32_supported(const ConvArgs& a, int tile) {
     return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && t32_lds_bytes(t, a.W, a.Cout_pad) <= 160 * 1024 / t.wgs_per_cu;
 }
 
+// split-K: tiles of `tile` on this layer, and the workspace floats `split` partial tiles of each need
+int conv_t32_splitk_tiles(const ConvArgs& a, int tile) {
+    const T32Tile& t = kT32Tiles[tile];
+    return ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+}
+size_t conv_t32_splitk_ws_floats(const ConvArgs& a, int tile, int split) {
+    const T32Tile& t = kT32Tiles[tile];
+    return (size_t)conv_t32_splitk_tiles(a, tile) * split * t.bm * t.bn;
+}
+bool conv_t32_splitk_supported(const ConvArgs& a, int tile, int split, int num_cus) {
+    if (!conv_t32_supported(a, tile) || split < 2 || split > a.Cin / 32) return false;
+    const T32Tile& t = kT32Tiles[tile];
+    return !t.epi && (long)conv_t32_splitk_tiles(a, tile) * split <= (long)num_cus * t.wgs_per_cu;
+}
+
 void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     if (tile < 0 || tile >= kNumT32Tiles) fail(RMR_ERR_INVALID_ARGUMENT, "conv_t32: tile %d out of range", tile);
     if (!conv_t32_supported(a, tile)) fail(RMR_ERR_LOGIC, "conv_t32: layer not supported by tile %d", tile);
@@ -514,7 +589,14 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     });
     const int rows = t32_rows(t.bm, a.W);
     const int lds = t32_lds_bytes(t, a.W, a.Cout_pad);
-    const int n_tiles = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    int n_tiles = ((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
+    if (a.split > 1) {
+        if (a.split > a.Cin / 32) a.split = a.Cin / 32;
+        if (!a.splitk_ws || !a.splitk_cnt) fail(RMR_ERR_LOGIC, "conv_t32: split-K needs a workspace");
+        if (t.epi) fail(RMR_ERR_LOGIC, "conv_t32: split-K runs on the lane-pair-store tiles");
+        if ((long)n_tiles * a.split > (long)ctx.num_cus * t.wgs_per_cu) fail(RMR_ERR_LOGIC, "conv_t32: split-K needs one workgroup slot per (tile, split)");
+        if (a.split > 1) n_tiles *= a.split;
+    }
     // persistent: at most wgs_per_cu workgroups per CU (a multiple of 8: a workgroup stays on its XCD), each walks tiles
     const int grid = std::min((n_tiles + 7) / 8 * 8, ctx.num_cus * t.wgs_per_cu);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
@@ -525,7 +607,10 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     const char* pname = "conv_igemm_f16";
     if (per_layer && ctx.prof.on) {
         char buf[64];
-        snprintf(buf, sizeof(buf), "conv n%d M%d N%d K%d k%d s%d g%d", a.N, a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
+        if (a.split > 1)
+            snprintf(buf, sizeof(buf), "conv n%d M%d N%d K%d k%d s%d g%d/%d", a.N, a.M, a.Cout_pad, a.K, a.KH, a.stride, tile, a.split);
+        else
+            snprintf(buf, sizeof(buf), "conv n%d M%d N%d K%d k%d s%d g%d", a.N, a.M, a.Cout_pad, a.K, a.KH, a.stride, tile);
         std::lock_guard<std::mutex> lk(name_mu);
         pname = names.emplace(buf, buf).first->second.c_str();
     }

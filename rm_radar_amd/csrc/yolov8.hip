@@ -663,6 +663,11 @@ void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
     } else if (c >= 900) {
         launch_conv_t32f8(ctx_, s, a, c - 900);
     } else if (c >= 800) {
+        if (split > 1) {
+            a.split = split;
+            a.splitk_ws = splitk_ws_.p;
+            a.splitk_cnt = splitk_cnt_.p;
+        }
         launch_conv_t32(ctx_, s, a, c - 800);
     } else if (c >= 700) {
         launch_conv_pw(ctx_, s, a, c - 700);
@@ -745,6 +750,19 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a) {
                 if (split > nk / 2 || (long)tiles * split > 4L * ctx_.num_cus) break;
                 if (conv_dma_splitk_ws_floats(a, t, split) > kSplitKWsFloats) break;
                 cands.push_back(1000 * split + 100 + t);
+            }
+        }
+    // ... and of conv_t32 (round 3): a 3x3 layer of a batch of 1-4 images is 7-100 tiles of 256 pixels on 256 CUs, each
+    // streaming all 54-81 weight slices; with split-K every CU takes a few chunks of one tile
+    if (conv_t32_supported(a, -1))
+        for (int t = 0; t < conv_t32_num_tiles(); ++t) {
+            if (!conv_t32_supported(a, t)) continue;
+            const int tiles = conv_t32_splitk_tiles(a, t);
+            if (tiles >= ctx_.num_cus || tiles > kSplitKMaxTiles) continue;
+            for (int split : {2, 3, 4, 6, 9}) {
+                if (!conv_t32_splitk_supported(a, t, split, ctx_.num_cus)) continue;
+                if (conv_t32_splitk_ws_floats(a, t, split) > kSplitKWsFloats) break;
+                cands.push_back(1000 * split + 800 + t);
             }
         }
     // RMR_TUNE_ONLY=lo-hi: layers that have candidates in that id range choose among those only (tests
@@ -841,6 +859,9 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
     if (choice < 0) return false;
     const int c = choice % 1000, split = choice / 1000;
     const bool slabbed = a.in_slab_c || a.out_slab_c;
+    if (split && c >= 800 && c < 900)
+        return !slabbed && !a.in8 && c - 800 < conv_t32_num_tiles() && conv_t32_splitk_supported(a, c - 800, split, ctx_.num_cus) &&
+               conv_t32_splitk_tiles(a, c - 800) <= kSplitKMaxTiles && conv_t32_splitk_ws_floats(a, c - 800, split) <= kSplitKWsFloats;
     if (split) {
         if (split > 64 || c < 100 || c >= 200 || slabbed || !conv_dma_supported(a) || c - 100 >= conv_dma_num_tiles()) return false;
         const ConvTile ct = conv_dma_tile(c - 100);
@@ -864,8 +885,8 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
 }
 
 // header: "rmr-tune <version> <ops> <w> <h> <plan signature> <CUs> <device name without blanks>"
-// (the version moves whenever the set of candidate kernels does: 11 = conv_g32 added, 12 = conv_w1d)
-static constexpr int kTuneFileVersion = 12;
+// (the version moves whenever the set of candidate kernels does: 11 = conv_g32 added, 12 = conv_w1d, 13 = split-K conv_t32)
+static constexpr int kTuneFileVersion = 13;
 static std::string device_tag(int device) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return "unknown";

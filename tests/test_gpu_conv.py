@@ -288,6 +288,18 @@ def test_conv_t32_every_tile(rmr):
     run_case(rmr, 330, 20, 20, 32, 96, 3, 1, True, False, tile=806, seed=78)  # 516 tiles on 512 workgroups: a few walk two
     run_case(rmr, 200, 20, 20, 64, 192, 3, 1, True, True, tile=809, seed=79)  # 625 tiles of 128 x 192 on 512 four-wave workgroups
     run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, True, tile=810, seed=80)     # four-wave 256 x 96 on 80-wide maps
+    # split-K (ids 1000 * split + 800 + tile; batches of 1-4 images): one workgroup per (tile, range of chunks), the partial
+    # tiles summed in split order by the last arriver; launched twice by the test entry point (the tickets re-arm themselves)
+    run_case(rmr, 4, 40, 40, 192, 192, 3, 1, True, True, tile=3000 + 812, seed=90)    # 25 x 3 tiles x 3 splits of 2 chunks
+    run_case(rmr, 1, 40, 40, 192, 192, 3, 1, True, False, tile=6000 + 812, seed=91)   # one chunk per workgroup
+    run_case(rmr, 4, 20, 20, 288, 288, 3, 1, True, True, tile=9000 + 810, seed=92)    # 7 x 3 tiles x 9 splits
+    run_case(rmr, 1, 20, 20, 288, 288, 3, 1, True, False, tile=4000 + 810, seed=93)   # 9 chunks over 4 workgroups: 2, 2, 2, 3
+    run_case(rmr, 4, 80, 80, 96, 96, 3, 1, True, True, tile=3000 + 810, seed=94)      # 100 tiles x 3 on 512 slots
+    run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, False, tile=2000 + 803, seed=95)     # 13 tiles of 512 x 96, chunks 1 + 2
+    run_case(rmr, 1, 19, 23, 64, 192, 3, 1, True, True, tile=2000 + 809, seed=96)     # ragged M
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((64, 40, 40, 64), np.float32), np.zeros((192, 64, 3, 3), np.float32), None, 1, 1,
+                   False, tile=2000 + 812)  # 1200 workgroups: no slot per (tile, split)
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 4, 4, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1,
                    False, tile=806)  # Cin = 48 is not a multiple of 32
