@@ -2,7 +2,9 @@
 """Does the GPU run faster when a step's frames go through L independent detector lanes (own streams, B / L frames
 each) than through one?  Kernels of different lanes overlap, so the tail round of one layer's tiles (1.56 rounds
 of 256 x 192 tiles on the 40 x 40 level at 64 images) is filled by the other lane's tiles.
-usage: lanes_experiment.py [lanes ...]   (default 1 2 4)"""
+usage: lanes_experiment.py [lanes ...]   (default 1 2 4)
+RMR_LANES_FULL=1: every lane runs the WHOLE batch (L batches in flight, same launch sizes as one lane): the upper bound of what
+overlapping one step's car stage with the previous step's armor stage could give."""
 import os
 import sys
 import time
@@ -33,8 +35,9 @@ d_images = torch.from_numpy(images).to(dev)
 d_clouds = torch.from_numpy(clouds).to(dev)
 B, K = args.batch, args.crops
 forced_all = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(B, -1, 4))
+FULL = os.environ.get("RMR_LANES_FULL", "0") not in ("", "0")
 for L in lanes_list:
-    n = B // L
+    n = B if FULL else B // L
     lanes = []
     for l in range(L):
         packs = (os.path.join(pack_dir, f"car_l{L}_{l}.rmrw"), os.path.join(pack_dir, f"armor_l{L}_{l}.rmrw"))
@@ -42,8 +45,9 @@ for L in lanes_list:
         W.make_synthetic_pack(packs[1], "m", 12, seed=2, cls_bias=-6.0)
         rdet = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=K, opt_cars=K, device=0, max_frames=n)
         loc = rmr.Locator(size[0], size[1], bench.intrinsic(args), scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), device=0, max_frames=n)
-        fb = rmr.FrameBatch([d_images[f] for f in range(l * n, (l + 1) * n)], [d_clouds[f] for f in range(l * n, (l + 1) * n)])
-        lanes.append((rdet, loc, fb, np.ascontiguousarray(forced_all[l * n:(l + 1) * n])))
+        lo = 0 if FULL else l * n
+        fb = rmr.FrameBatch([d_images[f] for f in range(lo, lo + n)], [d_clouds[f] for f in range(lo, lo + n)])
+        lanes.append((rdet, loc, fb, np.ascontiguousarray(forced_all[lo:lo + n])))
     pool = ThreadPoolExecutor(max_workers=L)
 
     def step():
@@ -60,7 +64,8 @@ for L in lanes_list:
         steps += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"lanes {L}: {steps * B / dt:8.1f} frames/s  ({dt / steps * 1e3:.2f} ms per {B}-frame step)", flush=True)
+    fr = B * (L if FULL else 1)
+    print(f"lanes {L}{' (full batches)' if FULL else ''}: {steps * fr / dt:8.1f} frames/s  ({dt / steps * 1e3:.2f} ms per {fr}-frame step)", flush=True)
     for rdet, loc, fb, fc in lanes:
         rdet.close()
         loc.close()
