@@ -400,6 +400,12 @@ void Yolov8::compact_arenas() {
                 break;
         }
     }
+    // RMR_FP8_FUSE=1: an e4m3 buffer written by a producing layer's epilogue holds that layer's Cout channels only -- the bytes
+    // between Cout and the row pitch must stay the zeros of the arena's one-time memset (the consumer's last 64-channel chunk
+    // reads them), so such a buffer never shares memory with another (a quantiser pass rewrites the whole pitch: those share)
+    for (const Op& op : ops_)
+        if (op.kind == OP_CONV && op.q_out)
+            if (Block* b = block_of(2, op.q_out_off)) b->first = 0, b->last = (int)ops_.size() - 1;
     // first fit in order of first use: a block may take the memory of blocks that died before it is born
     size_t top[3] = {0, 0, 0};
     std::vector<Block*> order;
