@@ -71,10 +71,8 @@ Detector::Detector(const rmr_detector_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg
     net_ = std::make_unique<Yolov8>(ctx_, cfg.engine_path, cfg.classes, cfg.input_width, cfg.input_height,
                                     cfg.max_batch_size, cfg.precision == RMR_PRECISION_FP8);
     const int B = cfg.max_batch_size;
-    descs_dev_.alloc(B);
-    pp_dev_.alloc(B);
-    descs_pin_.alloc(B);
-    pp_pin_.alloc(B);
+    io_dev_.alloc(pp_offset(B) + (size_t)B * sizeof(rmr_preparam));
+    io_pin_.alloc(io_dev_.n);
     post_scratch_.alloc(postprocess_scratch_bytes(B, net_->anchors()));
     det_cap_ = net_->anchors();  // every anchor can survive, as in the reference (detector.cu:549)
     dets_dev_.alloc((size_t)B * det_cap_);
@@ -105,16 +103,15 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
         LetterboxDesc& d = descs[i];
         const rmr_preparam p = make_preparam(d.crop_w, d.crop_h, cfg_.input_width, cfg_.input_height);
         letterbox_geometry(p, d.rw, d.rh, d.top, d.left);
-        descs_pin_.p[i] = d;
-        pp_pin_.p[i] = p;
+        descs_pin()[i] = d;
+        pp_pin(n)[i] = p;
     }
-    RMR_HIP(hipMemcpyAsync(descs_dev_.p, descs_pin_.p, n * sizeof(LetterboxDesc), hipMemcpyHostToDevice, stream_));
-    RMR_HIP(hipMemcpyAsync(pp_dev_.p, pp_pin_.p, n * sizeof(rmr_preparam), hipMemcpyHostToDevice, stream_));
+    RMR_HIP(hipMemcpyAsync(io_dev_.p, io_pin_.p, pp_offset(n) + (size_t)n * sizeof(rmr_preparam), hipMemcpyHostToDevice, stream_));
     // letterbox (fill 128, 1/255) + network; the first layer samples the frames itself where it can
-    net_->forward(stream_, n, descs_dev_.p, 128, 1 / 255.f);
+    net_->forward(stream_, n, descs_dev(), 128, 1 / 255.f);
     if (!post) return;
     launch_postprocess(ctx_, stream_, net_->output(), n, net_->channels(), net_->anchors(), net_->nc(),
-                       cfg_.nms_thresh, cfg_.conf_thresh, pp_dev_.p, post_scratch_.p, dets_dev_.p,
+                       cfg_.nms_thresh, cfg_.conf_thresh, pp_dev(n), post_scratch_.p, dets_dev_.p,
                        counts_dev_.p, det_cap_);
     // D2H: the first kHeadRows rows of every image and the counts, gathered on the device into one block and fetched
     // with ONE contiguous copy (the reference copies all 8400 rows of every image, detector.cu:549-551); images with
@@ -194,7 +191,7 @@ void Detector::infer(const rmr_image* imgs, const int* crops, int n, float* net_
                            hipMemcpyDeviceToHost, stream_));
     RMR_HIP(hipStreamSynchronize(stream_));
     if (pp)
-        for (int i = 0; i < n; ++i) pp[i] = pp_pin_.p[i];
+        for (int i = 0; i < n; ++i) pp[i] = pp_pin(n)[i];
 }
 
 int Detector::read_heads(int first, int n, float* out, rmr_preparam* pp) {
@@ -206,7 +203,7 @@ int Detector::read_heads(int first, int n, float* out, rmr_preparam* pp) {
     RMR_HIP(hipMemcpyAsync(out, net_->output() + (size_t)first * per, (size_t)n * per * sizeof(float), hipMemcpyDeviceToHost, stream_));
     RMR_HIP(hipStreamSynchronize(stream_));
     if (pp)
-        for (int i = 0; i < n; ++i) pp[i] = pp_pin_.p[first + i];
+        for (int i = 0; i < n; ++i) pp[i] = pp_pin(last_n_)[first + i];
     return last_n_;
 }
 

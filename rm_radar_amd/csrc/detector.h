@@ -59,13 +59,18 @@ class Detector {
     static constexpr int kHeadRows = 64;  // rows per image fetched with the counts
     int det_cap_ = 0;
     int last_n_ = 0;  // images of the last enqueue()
-    DevBuf<LetterboxDesc> descs_dev_;
-    DevBuf<rmr_preparam> pp_dev_;
+    // descriptors and letterbox parameters of a call travel as ONE block ([n descs][n params], one H2D copy: a small
+    // hipMemcpyAsync is a blit kernel of its own, ~4 us + a launch boundary in the batch-1 trace)
+    DevBuf<unsigned char> io_dev_;
+    PinnedBuf<unsigned char> io_pin_;
+    static size_t pp_offset(int n) { return ((size_t)n * sizeof(LetterboxDesc) + 15) & ~(size_t)15; }
+    LetterboxDesc* descs_dev() { return (LetterboxDesc*)io_dev_.p; }
+    LetterboxDesc* descs_pin() { return (LetterboxDesc*)io_pin_.p; }
+    rmr_preparam* pp_dev(int n) { return (rmr_preparam*)(io_dev_.p + pp_offset(n)); }
+    rmr_preparam* pp_pin(int n) { return (rmr_preparam*)(io_pin_.p + pp_offset(n)); }
     DevBuf<uint8_t> post_scratch_;
     DevBuf<rmr_detection> dets_dev_;
     DevBuf<int> counts_dev_;
-    PinnedBuf<LetterboxDesc> descs_pin_;
-    PinnedBuf<rmr_preparam> pp_pin_;
     DevBuf<uint8_t> heads_dev_;      // [B][kHeadRows] rows + B counts, gathered for one contiguous D2H copy
     PinnedBuf<uint8_t> heads_pin_;
 };

@@ -25,4 +25,8 @@ void launch_head_decode(DeviceCtx& ctx, hipStream_t s, const float* box, const f
                         int cls_cs, int nc, float* out, int N, int H, int W, int stride,
                         int a_off, int a_total);
 
+// up to three scales in one launch (the arithmetic of launch_head_decode, bit for bit); cls_cs is common to the scales
+void launch_head_decode3(DeviceCtx& ctx, hipStream_t s, int scales, const float* const* box, const float* const* cls, int cls_cs, int nc,
+                         float* out, int N, const int* H, const int* W, const int* stride, const int* a_off, int a_total);
+
 }  // namespace rmr

@@ -2,6 +2,8 @@
 // (8 x f16) accesses per lane, channels fastest so a wave touches contiguous lines.
 #include "net_ops.h"
 
+#include <algorithm>
+
 namespace rmr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -143,6 +145,74 @@ __global__ __launch_bounds__(256) void head_decode_kernel(const float* __restric
     o[(long)3 * a_total] = (y2 - y1) * st;
     const float* c = cls + idx * cls_cs;
     for (int j = 0; j < nc; ++j) o[(long)(4 + j) * a_total] = 1.0f / (1.0f + __expf(-c[j]));
+}
+
+// the same over up to three scales in ONE launch (blockIdx.y = scale): at batch 1-4 a scale is 2-25 workgroups and a launch
+// is mostly its fixed cost (three launches of ~5.4 us per forward in the batch-1 trace)
+struct HeadScales {
+    const float* box[3];
+    const float* cls[3];
+    int H[3], W[3], stride[3], a_off[3];
+};
+
+__global__ __launch_bounds__(256) void head_decode3_kernel(const HeadScales hs, int cls_cs, int nc, float* __restrict__ out, int N, int a_total) {
+    const int sc = blockIdx.y;
+    const int H = hs.H[sc], W = hs.W[sc];
+    const int hw = H * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * hw) return;
+    const int n = (int)(idx / hw);
+    const int a = (int)(idx % hw);
+    const float* b = hs.box[sc] + idx * 64;
+    float dist[4];
+#pragma unroll
+    for (int side = 0; side < 4; ++side) {
+        float v[16];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = *(const float4*)(b + side * 16 + q * 4);
+            v[q * 4 + 0] = t.x;
+            v[q * 4 + 1] = t.y;
+            v[q * 4 + 2] = t.z;
+            v[q * 4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, v[i]);
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __expf(v[i] - mx);
+            se += e;
+            sw += e * (float)i;
+        }
+        dist[side] = sw / se;
+    }
+    const float ax = (float)(a % W) + 0.5f, ay = (float)(a / W) + 0.5f;
+    const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+    const float st = (float)hs.stride[sc];
+    float* o = out + (long)n * (4 + nc) * a_total + hs.a_off[sc] + a;
+    o[0] = (x1 + x2) * 0.5f * st;
+    o[(long)a_total] = (y1 + y2) * 0.5f * st;
+    o[(long)2 * a_total] = (x2 - x1) * st;
+    o[(long)3 * a_total] = (y2 - y1) * st;
+    const float* c = hs.cls[sc] + idx * cls_cs;
+    for (int j = 0; j < nc; ++j) o[(long)(4 + j) * a_total] = 1.0f / (1.0f + __expf(-c[j]));
+}
+
+void launch_head_decode3(DeviceCtx& ctx, hipStream_t s, int scales, const float* const* box, const float* const* cls, int cls_cs, int nc,
+                         float* out, int N, const int* H, const int* W, const int* stride, const int* a_off, int a_total) {
+    if (scales < 1 || scales > 3) fail(RMR_ERR_LOGIC, "head_decode3: %d scales", scales);
+    HeadScales hs{};
+    long most = 0, total = 0;
+    for (int i = 0; i < scales; ++i) {
+        hs.box[i] = box[i], hs.cls[i] = cls[i], hs.H[i] = H[i], hs.W[i] = W[i], hs.stride[i] = stride[i], hs.a_off[i] = a_off[i];
+        most = std::max(most, (long)N * H[i] * W[i]);
+        total += (long)N * H[i] * W[i];
+    }
+    ProfScope ps(ctx.prof, s, "head_decode", 0, (double)total * (64 + cls_cs + 4 + nc) * 4);
+    head_decode3_kernel<<<dim3((unsigned)((most + 255) / 256), scales), 256, 0, s>>>(hs, cls_cs, nc, out, N, a_total);
+    RMR_HIP(hipGetLastError());
 }
 
 void launch_head_decode(DeviceCtx& ctx, hipStream_t s, const float* box, const float* cls,

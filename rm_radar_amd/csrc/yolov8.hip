@@ -583,6 +583,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     for (int i = 0; i < 3; ++i) anchors_ += feats[i].h * feats[i].w;
     int a_off = 0;
     const int cls_pad = (nc_ + 15) / 16 * 16;
+    std::vector<Op> head_ops;
     for (int i = 0; i < 3; ++i) {
         const View& f = feats[i];
         const std::string b = "model.22.cv2." + std::to_string(i), c = "model.22.cv3." + std::to_string(i);
@@ -603,9 +604,11 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
         op.head_stride = strides[i];
         op.a_off = a_off;
         op.in = f;
-        ops_.push_back(op);
+        head_ops.push_back(op);
         a_off += f.h * f.w;
     }
+    // the three scales' decodes go last, together: one launch (run_op), the logits live until then
+    for (const Op& op : head_ops) ops_.push_back(op);
 
     if (const char* e = std::getenv("RMR_ARENA_REUSE")) arena_reuse_ = atoi(e) != 0;
     if (arena_reuse_) compact_arenas();
@@ -1068,11 +1071,18 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
             launch_upsample2x(ctx_, s, hptr(op.in), op.in.cs, op.in.co, hptr(op.out), op.out.cs, op.out.co, n,
                               op.in.h, op.in.w, op.in.c);
             break;
-        case OP_HEAD:
-            launch_head_decode(ctx_, s, fptr(op.box), fptr(op.cls), op.cls.cs, nc_,
-                               output_.p + img0 * (size_t)(4 + nc_) * anchors_, n, op.in.h, op.in.w,
-                               op.head_stride, op.a_off, anchors_);
+        case OP_HEAD: {
+            // consecutive scales leave in one launch: the first of a run decodes the run, the others have nothing left to do
+            if (op_index > 0 && ops_[op_index - 1].kind == OP_HEAD) break;   // (the planner emits the three scales' decodes together)
+            const float *box[3], *cls[3];
+            int H[3], W[3], st[3], off[3], k = 0;
+            for (int i = op_index; i < (int)ops_.size() && k < 3 && ops_[i].kind == OP_HEAD && ops_[i].cls.cs == op.cls.cs; ++i, ++k) {
+                box[k] = fptr(ops_[i].box), cls[k] = fptr(ops_[i].cls);
+                H[k] = ops_[i].in.h, W[k] = ops_[i].in.w, st[k] = ops_[i].head_stride, off[k] = ops_[i].a_off;
+            }
+            launch_head_decode3(ctx_, s, k, box, cls, op.cls.cs, nc_, output_.p + img0 * (size_t)(4 + nc_) * anchors_, n, H, W, st, off, anchors_);
             break;
+        }
     }
 }
 
