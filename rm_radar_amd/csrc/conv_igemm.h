@@ -57,6 +57,7 @@ struct ConvArgs {
     // instead of by a quantiser pass); bytes beyond Cout stay as they are (the planner keeps them zero)
     unsigned char* out8;
     int out8_cs;
+    int out8_only;      // 1: the e4m3 rows are the ONLY output (the tensor's single reader is an e4m3 layer): no f16 store
     // split-K (conv_dma only): `split` workgroups share one output tile, each accumulating a
     // contiguous range of K slices; partial tiles meet in splitk_ws and the last arriver (ticket in
     // splitk_cnt, which it resets to 0) reduces them and runs the epilogue.  split <= 1: off.

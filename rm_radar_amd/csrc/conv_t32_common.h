@@ -68,10 +68,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 // bias is added; the scales are Cout_pad floats in LDS right behind the bias vector.
 // RS / row_off (conv_w1d): fragment row r of the tile is pixel RS * r + row_off (RS = 2: the rows are 2-pixel Winograd tiles and
 // the call stores their even or odd pixels); EPI = 0 only.
-template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE, bool SCALE = false, int AUX = 0, int RS = 1>
+// OUT8 (the fp8 plan; EPI = 0): 1 = the eight f16 values of a lane leave ONLY as e4m3 bytes in a.out8 (rows of a.out8_cs
+// bytes; rounded from the f16 value a quantiser pass over the stored tensor would read) -- for a tensor whose only reader
+// is an e4m3 layer: half the store bytes and no quantiser pass; 2 = as f16 AND as e4m3.  One more half exchange per
+// 32-channel block makes the e4m3 store 16 bytes per lane.
+template <int MREP, int NREP, int EPI, bool RES, bool BIAS_LDS, bool NOSTORE, bool SCALE = false, int AUX = 0, int RS = 1, int OUT8 = 0>
 __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)[MREP][NREP], unsigned char* smem, int stg_base, int bias_off,
                                               int m0, int n0, int wm, int wn, int lane, int row_off = 0) {
     static_assert(RS == 1 || EPI == 0, "strided rows leave through the lane-pair stores");
+    static_assert(OUT8 == 0 || (EPI == 0 && RS == 1), "the e4m3 copy leaves through the lane-pair stores");
     static_assert(!SCALE || BIAS_LDS, "scales live in LDS");
     constexpr int STG_PITCH = NREP * 64 + 16;   // bytes per pixel row of the epilogue stage
     const int fr = lane & 31, kq = lane >> 5;
@@ -86,6 +91,10 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
     const __amdgpu_buffer_rsrc_t out_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)((_Float16*)a.out + (long)mw0 * a.out_cs), 0, view_bytes(a.out_cs), 0x00020000);
     const unsigned out_lane = (unsigned)(RS * fr * a.out_cs + a.out_co + nw0 + kq * 8) * 2u;   // fragment row 0, channel group 0
+    const long b8 = rows_left * (OUT8 ? a.out8_cs : 0);
+    const __amdgpu_buffer_rsrc_t out8_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((unsigned char*)a.out8 + (OUT8 ? (long)mw0 * a.out8_cs : 0)), 0, (unsigned)(b8 <= 0 ? 0 : b8 > 0xfffffff0l ? 0xfffffff0l : b8), 0x00020000);
+    const unsigned out8_lane = (unsigned)(fr * (OUT8 ? a.out8_cs : 0) + nw0 + kq * 16);
     // ---- every load of the epilogue, ahead of its first store ------------------------------------------------
     float4 bias[BIAS_LDS ? 1 : NREP][BIAS_LDS ? 1 : 4];
     if constexpr (!BIAS_LDS) {
@@ -114,7 +123,8 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
         // 8 gq + 8 + {0..3 | 4..7}: one v_permlane32_swap per dword gives the lower lane all eight channels of
         // group gq and the upper lane those of group gq + 1.
 #pragma unroll
-        for (int j = 0; j < NREP; ++j)
+        for (int j = 0; j < NREP; ++j) {
+            unsigned q8[2] = {0u, 0u};   // the e4m3 bytes of group pair 0, until group pair 1 completes the 32-channel block
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 float v[8];
@@ -175,7 +185,27 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
                     o.w[2] = s0[1];
                     o.w[3] = s1[1];
                 }
-                if constexpr (EPI == 0) {
+                if constexpr (OUT8 != 0) {
+                    const auto sat = [](_Float16 x) { return __builtin_amdgcn_fmed3f((float)x, -448.f, 448.f); };
+                    int w0 = 0, w1 = 0;
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(o.h[0]), sat(o.h[1]), w0, false);
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(o.h[2]), sat(o.h[3]), w0, true);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(o.h[4]), sat(o.h[5]), w1, false);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat(o.h[6]), sat(o.h[7]), w1, true);
+                    if (gp == 0) {
+                        q8[0] = (unsigned)w0, q8[1] = (unsigned)w1;
+                    } else {
+                        // lane pair (l, l + 32) holds channels [0..7 | 8..15] of group pair 0 and [16..23 | 24..31] of group pair
+                        // 1: after the exchange the lower lane has bytes 0..15 and the upper lane bytes 16..31 of the block
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(q8[0], (unsigned)w0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(q8[1], (unsigned)w1, false, false);
+                        const u32x4 q = kq ? u32x4{s0[0], s1[0], (unsigned)w0, (unsigned)w1} : u32x4{q8[0], q8[1], s0[1], s1[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(q, out8_rsrc, out8_lane + (unsigned)(i * 32 * a.out8_cs + j * 32), 0, AUX);
+                    }
+                }
+                if constexpr (OUT8 == 1) {
+                    // no f16 copy: the tensor's only reader takes the e4m3 bytes
+                } else if constexpr (EPI == 0) {
                     if constexpr (NOSTORE)
                         asm volatile("" : : "v"(o.u));
                     else
@@ -184,6 +214,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx16 (&acc)
                     *(u32x4*)(smem + stg_base + fr * STG_PITCH + (j * 32 + gp * 16 + kq * 8) * 2) = o.u;
                 }
             }
+        }
         if constexpr (EPI == 1) {
             // the wave's 32 x (NREP * 32) block leaves as whole rows: NREP * 4 lanes per pixel
             constexpr int CPP = NREP * 4;   // 16-byte chunks per pixel

@@ -356,8 +356,18 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
         const bool wide = !a.out32 && ((a.out_cs | a.out_co) & 7) == 0;   // 16-byte stores need 8-channel alignment
         // the usual case (SiLU, no e4m3 copy of the output): the shared epilogue -- every load ahead of the first store,
         // bias and scales from LDS (conv_t32_common.h)
-        const bool fast = wide && a.act && !a.out8 && (!a.res || (NREP < 4 && ((a.res_cs | a.res_co) & 7) == 0));
-        if (fast) {
+        const bool fast = wide && a.act && (!a.out8 || EPI == 0) && (!a.res || (NREP < 4 && ((a.res_cs | a.res_co) & 7) == 0));
+        if (fast && a.out8) {
+            // the output (also / only) as the next e4m3 layer's input, written here instead of by a quantiser pass
+            if constexpr (EPI == 0) {
+                if (a.out8_only)
+                    t32::epilogue_wide<MREP, NREP, 0, false, true, false, true, 0, 1, 1>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+                else if (NREP < 4 && a.res)
+                    t32::epilogue_wide<MREP, NREP, 0, (NREP < 4), true, false, true, 0, 1, 2>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+                else
+                    t32::epilogue_wide<MREP, NREP, 0, false, true, false, true, 0, 1, 2>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+            }
+        } else if (fast) {
             if (NREP < 4 && a.res)
                 t32::epilogue_wide<MREP, NREP, EPI, (NREP < 4), true, false, true>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
             else

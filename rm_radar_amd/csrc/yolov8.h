@@ -94,6 +94,7 @@ class Yolov8 {
         int q_pitch = 0;
         // OP_CONV of the fp8 plan whose output feeds another e4m3 layer: it writes that layer's input itself
         bool q_out = false;
+        bool q_only = false;   // ... and nothing else reads the tensor: its f16 copy is not written
         size_t q_out_off = 0;
         int q_out_pitch = 0;
         int stride = 1, act = 1;

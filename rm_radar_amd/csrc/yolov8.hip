@@ -236,10 +236,12 @@ void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act
         arena_bytes8_ = (arena_bytes8_ + 255) & ~(size_t)255;
         allocs_.push_back(Alloc{q.q_off, arena_bytes8_ - q.q_off, 2, 0});
         // The e4m3 copy is written by a quantiser pass (read 2 B, write 1 B per value at ~3.9 TB/s: 2.1 ms of a
-        // 256-image forward).  RMR_FP8_FUSE=1: when the tensor comes out of an e4m3 layer, that layer's epilogue writes
-        // it instead -- measured a wash (26.2 vs 26.0 ms): the epilogue is store-issue bound, and its extra 16-byte
-        // stores over 32 pixel rows cost the 96-channel layers 18 % (901 -> 741 TFLOP/s), as much as the passes saved.
-        static const bool fuse = std::getenv("RMR_FP8_FUSE") && atoi(std::getenv("RMR_FP8_FUSE")) != 0;
+        // 256-image forward, 36 launches) -- unless the tensor comes out of an e4m3 layer: then that layer's epilogue writes
+        // it (conv_t32_common.h, OUT8), and where this layer is the tensor's ONLY reader (the hidden tensor of a
+        // bottleneck) the f16 copy is not written at all (q_only, decided once the plan is complete).  Round 2 had
+        // measured the fused form a wash: it ran through the old epilogue, bias loads between the stores.  RMR_FP8_FUSE=0
+        // restores the passes.
+        static const bool fuse = !(std::getenv("RMR_FP8_FUSE") && atoi(std::getenv("RMR_FP8_FUSE")) == 0);
         Op* producer = nullptr;
         for (auto it = ops_.rbegin(); it != ops_.rend() && fuse; ++it)
             if (it->kind == OP_CONV && it->out.off == in.off && it->out.co == in.co && it->out.c == in.c && it->out.cs == in.cs) {
@@ -610,7 +612,33 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     // the three scales' decodes go last, together: one launch (run_op), the logits live until then
     for (const Op& op : head_ops) ops_.push_back(op);
 
+    // fp8 plan: a tensor that leaves its producer as e4m3 (q_out) and has no other reader than the e4m3 layer behind it
+    // is never written as f16 (the stage-output hook, RMR_ARENA_REUSE=0, keeps every f16 tensor)
     if (const char* e = std::getenv("RMR_ARENA_REUSE")) arena_reuse_ = atoi(e) != 0;
+    for (size_t pi = 0; pi < ops_.size() && arena_reuse_; ++pi) {
+        Op& p = ops_[pi];
+        if (p.kind != OP_CONV || !p.q_out) continue;
+        const auto reads = [&](const View& v) { return (v.c || v.cs) && v.off == p.out.off && v.co < p.out.co + p.out.c && p.out.co < v.co + v.c; };
+        bool only = true;
+        int readers = 0;
+        for (size_t i = 0; i < ops_.size() && only; ++i) {
+            if (i == pi) continue;
+            const Op& o = ops_[i];
+            if (o.kind == OP_CONV && reads(o.in) && !o.in_is_input) {
+                if (o.fp8 && o.q_off == p.q_out_off && !reads(o.res) && !reads(o.pre)) ++readers;
+                else only = false;
+            } else if ((o.kind != OP_CONV && reads(o.in)) || reads(o.res) || reads(o.pre) || (o.kind == OP_UP && reads(o.out))) {
+                only = false;
+            }
+            if (o.in_slab_c || o.out_slab_c) {   // a slabbed 1x1 names the first slab only: any slab of its group may be ours
+                const size_t lo = o.in_slab_c ? o.in.off : o.out.off, step = o.in_slab_c ? o.in_slab_step : o.out_slab_step;
+                const int cnt = o.in_slab_c ? o.in.c / o.in_slab_c : o.out.c / o.out_slab_c;
+                for (int k = 0; k < cnt; ++k) only = only && lo + k * step != p.out.off;
+            }
+        }
+        for (const auto& kv : named_) only = only && kv.second.v.off != p.out.off;
+        p.q_only = only && readers == 1;
+    }
     if (arena_reuse_) compact_arenas();
     // Images per launch: every activation view (pixels x its buffer's channel pitch, plus the span of its
     // slabs) must stay below the 32-bit offset range of the kernels' buffer resources.  256 images of a
@@ -856,7 +884,7 @@ unsigned long long Yolov8::plan_signature() const {
     unsigned long long h = 1469598103934665603ull;
     const auto mix = [&](long long v) { h = (h ^ (unsigned long long)v) * 1099511628211ull; };
     for (const Op& op : ops_) {
-        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs), mix(op.fp8), mix(op.q_pitch), mix(op.q_out);
+        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs), mix(op.fp8), mix(op.q_pitch), mix(op.q_out), mix(op.q_only);
         if (op.kind == OP_CONV) mix(convs_[op.conv].K), mix(convs_[op.conv].cout_pad);
     }
     return h;
@@ -1019,6 +1047,7 @@ ConvArgs Yolov8::conv_args(int op_index, int n, size_t img0) {
         if (op.q_out) {
             a.out8 = arena8_.p + op.q_out_off * chunk_;
             a.out8_cs = op.q_out_pitch;
+            a.out8_only = op.q_only ? 1 : 0;
         }
     }
     a.flops = 2.0 * a.M * (double)cw.cout * (op.in_is_input ? 3 : cw.cin) * cw.k * cw.k;
