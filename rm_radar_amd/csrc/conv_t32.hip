@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int stg_base = zero_off + 1024 + wave * 32 * STG_PITCH;
-    const int bias_off = zero_off + 1024 + (EPI ? NW * 32 * STG_PITCH : 0);   // Cout_pad floats
+    const int bias_off = zero_off + 1024 + (EPI == 1 ? NW * 32 * STG_PITCH : 0);   // Cout_pad floats
 
     // tile vb -> (m0, n0); XCD-aware: the tiles of one XCD (vb & 7) are a contiguous range, n-tiles innermost
     const int nt_count = a.Cout_pad / BN;
@@ -464,7 +464,12 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
 #endif
                 }
         } else {
-            epilogue<MREP, NREP, EPI, true, (NREP < 4 && MREP * NREP <= 8), (ABL & 4) != 0, (ABL & 256) ? 2 : 0>(a, acc, smem, stg_base, bias_off, m0, n0, wm, wn, lane);
+            // EPI = 2: rows staged through the input buffer the tile's last chunk has just finished with (the other one is
+            // receiving the next tile's first range; this one is not written again before every wave has passed the next
+            // tile's first barrier): whole-row stores for the tiles that have no LDS to spare for a stage of their own
+            if constexpr (EPI == 2) __builtin_amdgcn_s_barrier();   // every wave has read its last fragments from that buffer
+            const int stg = EPI == 2 ? (a_buf_bytes - abuf) + wave * 32 * STG_PITCH : stg_base;
+            epilogue<MREP, NREP, (EPI == 2 ? 1 : EPI), true, (NREP < 4 && MREP * NREP <= 8), (ABL & 4) != 0, (ABL & 256) ? 2 : 0>(a, acc, smem, stg, bias_off, m0, n0, wm, wn, lane);
         }
 
         if (!has_next) break;
@@ -790,8 +795,11 @@ const T32Tile kT32Tiles[] = {
     // (tried: ONE four-wave workgroup per CU with a 128 x 96 wave tile, T32(2, 2, 4, 3, 4, 5, 0, 1) -- 192 accumulators, 7
     // fragment reads per 12 MFMAs instead of 10, one wave per SIMD: 304.4 us against 303.1 on M409600 N192 K1728.  Half the
     // waves, 30 % fewer LDS reads, the same time: the K loop sits at the package power limit, not at a pipe.)
+    // whole-row stores for the two-per-CU tiles: rows staged through the input buffer the last chunk is done with
+    T32(4, 1, 2, 3, 4, 4, 2, 2),    // 13: tile 10 (256 x 96), where that buffer holds the wave stages (80-wide maps)
+    T32(2, 2, 2, 3, 2, 4, 2, 2),    // 14: tile 9 (128 x 192)
 #ifdef RMR_T32_PINGPONG
-    // 13..16 (development builds): the ping-pong form
+    // 15.. (development builds): the ping-pong form
     { 256, 192, 512, 4, 5, 3, 0, 1, conv_t32pp_kernel<4, 2, 2, 3, 4, 5, 0> },     // 13: 256 x 192
     { 256, 192, 512, 4, 4, 3, 0, 1, conv_t32pp_kernel<4, 2, 2, 3, 4, 4, 0> },     // 14: up to 80-wide maps
     { 512, 96, 512, 10, 5, 3, 0, 1, conv_t32pp_kernel<8, 1, 2, 3, 10, 5, 0> },    // 15: 512 x 96
@@ -833,7 +841,7 @@ constexpr int kNumT32Tiles = sizeof(kT32Tiles) / sizeof(kT32Tiles[0]);
 
 int t32_rows(int bm, int W) { return (bm + 2 * W + 2 + 15) / 16 * 16; }
 int t32_lds_bytes(const T32Tile& t, int W, int cout_pad) {
-    return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + (t.epi ? (t.threads / 64) * 32 * (t.nrep * 64 + 16) : 0) + cout_pad * 4 + 16;
+    return 2 * t32_rows(t.bm, W) * 64 + t.ring * t.bn * 64 + 1024 + (t.epi == 1 ? (t.threads / 64) * 32 * (t.nrep * 64 + 16) : 0) + cout_pad * 4 + 16;
 }
 
 }  // namespace
@@ -847,6 +855,7 @@ bool conv_t32_supported(const ConvArgs& a, int tile) {
     if (tile < 0) return true;
     const T32Tile& t = kT32Tiles[tile];
     const int na = t32_rows(t.bm, a.W) / 16;
+    if (t.epi == 2 && (t.threads / 64) * 32 * (t.nrep * 64 + 16) > t32_rows(t.bm, a.W) * 64) return false;   // the stage lives in one input buffer
     return a.Cout_pad % t.bn == 0 && na <= t.a_slots * (11 - t.ring) && t32_lds_bytes(t, a.W, a.Cout_pad) <= 160 * 1024 / t.wgs_per_cu;
 }
 

@@ -271,8 +271,12 @@ def test_conv_t32_every_tile(rmr):
     # continuous DMA stream, weights pre-packed as LDS images, fragment reads ahead of the MFMAs across the
     # barrier, lane masks for the border taps, 16-byte stores (lane-pair exchange or rows staged through LDS)
     tiles = [(256, 192), (256, 192), (256, 192), (512, 96), (256, 256), (512, 64), (256, 96), (256, 64), (128, 192),
-             (128, 192), (256, 96), (128, 128), (256, 64)]   # 9..12: two four-wave workgroups per CU
-    for t, (bm, bn) in enumerate(tiles):
+             (128, 192), (256, 96), (128, 128), (256, 64),   # 9..12: two four-wave workgroups per CU
+             None, None]                                      # 13, 14: tiles 10 / 9 with rows staged through an input buffer (wide maps only)
+    for t, shape in enumerate(tiles):
+        if shape is None:
+            continue
+        bm, bn = shape
         run_case(rmr, 3, 20, 20, 64, bn, 3, 1, True, True, tile=800 + t, seed=t)            # 3 images in ~5 tiles
         run_case(rmr, 1, 19, 23, 32, bn * 2, 3, 1, True, False, tile=800 + t, seed=40 + t)  # odd W, ragged M, 1 chunk
     run_case(rmr, 2, 40, 40, 192, 192, 3, 1, True, True, tile=800, seed=70)   # 6 chunks, 54 taps
@@ -288,6 +292,9 @@ def test_conv_t32_every_tile(rmr):
     run_case(rmr, 330, 20, 20, 32, 96, 3, 1, True, False, tile=806, seed=78)  # 516 tiles on 512 workgroups: a few walk two
     run_case(rmr, 200, 20, 20, 64, 192, 3, 1, True, True, tile=809, seed=79)  # 625 tiles of 128 x 192 on 512 four-wave workgroups
     run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, True, tile=810, seed=80)     # four-wave 256 x 96 on 80-wide maps
+    run_case(rmr, 2, 80, 80, 96, 96, 3, 1, True, True, tile=813, seed=81)     # ... with rows staged through the spent input buffer
+    run_case(rmr, 3, 80, 80, 64, 192, 3, 1, True, False, tile=813, seed=82)   # 150 tiles, two channel tiles
+    run_case(rmr, 40, 80, 80, 32, 96, 3, 1, True, True, tile=813, seed=83)    # 1000 tiles on 512 workgroups: the stage meets the next tile's DMAs
     # split-K (ids 1000 * split + 800 + tile; batches of 1-4 images): one workgroup per (tile, range of chunks), the partial
     # tiles summed in split order by the last arriver; launched twice by the test entry point (the tickets re-arm themselves)
     run_case(rmr, 4, 40, 40, 192, 192, 3, 1, True, True, tile=3000 + 812, seed=90)    # 25 x 3 tiles x 3 splits of 2 chunks
