@@ -241,7 +241,7 @@ void Yolov8::conv(int widx, const View& in, const View& out, int stride, int act
         // bottleneck) the f16 copy is not written at all (q_only, decided once the plan is complete).  Round 2 had
         // measured the fused form a wash: it ran through the old epilogue, bias loads between the stores.  RMR_FP8_FUSE=0
         // restores the passes.
-        static const bool fuse = !(std::getenv("RMR_FP8_FUSE") && atoi(std::getenv("RMR_FP8_FUSE")) == 0);
+        const bool fuse = !(std::getenv("RMR_FP8_FUSE") && atoi(std::getenv("RMR_FP8_FUSE")) == 0);   // read per detector
         Op* producer = nullptr;
         for (auto it = ops_.rbegin(); it != ops_.rend() && fuse; ++it)
             if (it->kind == OP_CONV && it->out.off == in.off && it->out.co == in.co && it->out.c == in.c && it->out.cs == in.cs) {

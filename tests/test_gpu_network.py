@@ -510,6 +510,23 @@ def test_fp8_plan_at_its_own_batch_of_256(rmr, packs, images):
     assert np.abs(got[:3] - want16).max() > 0.05      # e4m3 layers did run
 
 
+def test_fp8_fused_e4m3_outputs_equal_the_quantiser_passes(rmr, packs, images, monkeypatch):
+    """Round 3: an e4m3 layer's epilogue writes the next e4m3 layer's input itself, and the hidden tensor of a bottleneck
+    (read by nobody else) is never written as f16.  The bytes are the ones the quantiser pass wrote (e4m3 of the f16-rounded
+    value), so with the kernel choice fixed (RMR_AUTOTUNE=0: the same tile per layer in both plans, hence the same f32
+    summation order) the network output must be BIT-IDENTICAL with and without the fusion (RMR_FP8_FUSE=0)."""
+    monkeypatch.setenv("RMR_AUTOTUNE", "0")
+    fused = rmr.Detector(packs[1], 12, (1920, 1080), 3, precision="fp8")
+    got, _ = fused.infer(images)
+    fused.close()
+    monkeypatch.setenv("RMR_FP8_FUSE", "0")
+    passes = rmr.Detector(packs[1], 12, (1920, 1080), 3, precision="fp8")
+    want, _ = passes.infer(images)
+    passes.close()
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, want), f"max difference {np.abs(got - want).max()}"
+
+
 def test_fp8_plan_decides_per_layer_and_runs_untuned(rmr, packs, images, tmp_path, monkeypatch):
     """The fp8 plan gives a layer e4m3 operands only where an e4m3 tile exists for its width on maps of its size
     (conv_t32f8_first_tile at plan time): a yolov8x-width pack has 160-channel 3x3 layers no tile divides -- they stay f16,
