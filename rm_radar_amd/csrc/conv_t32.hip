@@ -99,16 +99,31 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     // workgroup per (tile, split), so nobody walks on to a second tile
     const int split = a.split > 1 ? a.split : 1;
     int zsplit = 0, tile_id = 0;
-    const auto tile_m0n0 = [&](int vb, int& m0, int& n0) {
-        const int xcd = vb & 7;
-        const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+    // The walk (vb = this workgroup's k-th tile): the tiles of an XCD are a contiguous range of logical ids; a workgroup takes
+    // every (G / 8)-th tile of that range (the default), or (RMR_T32_WALK=1, an experiment of round 3) a CONTIGUOUS block of
+    // it, so that its consecutive tiles are the channel tiles of one pixel range and the neighbouring ranges, whose input
+    // rows it has just pulled into its XCD's L2.  Why it was tried -- -DRMR_T32_ABLATE on M1638400 N96 K864, tile 10: full 368
+    // us, input DMAs out of range 257, weight DMAs out of range 304, all DMAs out of range (instructions still issued) 232,
+    // no counted waits 368, and without epilogue AND DMA data 187 = the MFMAs alone (197): what the K loop loses is the DATA
+    // PATH of the LDS-DMAs (the input's 64-byte segments most of all), not their issue and not the waits.  What it gave:
+    // 308 -> 302 us on M409600 N192 K1728, 355 -> 359 on the 96-channel layer, 1887-1891 -> 1869-1871 frames/s in the bench
+    // (neighbouring tiles already run side by side on neighbouring workgroups of one XCD and share the L2 fill).
+    const bool walk_contig = (stagger >> 20) & 1;
+    const int my_xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, Gx = G >> 3;
+    const int cnt_x = q8 + (my_xcd < r8 ? 1 : 0);
+    const int base_x = my_xcd < r8 ? my_xcd * (q8 + 1) : r8 * (q8 + 1) + (my_xcd - r8) * q8;
+    const int per_lo = cnt_x / Gx, per_rem = cnt_x - per_lo * Gx;
+    const int my_first = jx * per_lo + min(jx, per_rem), my_cnt = per_lo + (jx < per_rem ? 1 : 0);
+    const auto tile_valid = [&](int k) { return walk_contig ? k < my_cnt : jx + k * Gx < cnt_x; };
+    const auto tile_m0n0 = [&](int k, int& m0, int& n0) {
+        const int lid = base_x + (walk_contig ? my_first + k : jx + k * Gx);
         tile_id = lid / split;
         zsplit = lid - tile_id * split;
         m0 = (tile_id / nt_count) * BM;
         n0 = (tile_id % nt_count) * BN;
     };
-    int vb = blockIdx.x;
-    if (vb >= n_tiles) return;
+    int vb = 0;
+    if (!tile_valid(0)) return;
     int m0, n0;
     tile_m0n0(vb, m0, n0);
     const int my_tile = tile_id, my_z = zsplit;
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     // prio (RMR_T32_PRIO, default 1): 1 = the K loop runs at s_setprio 1 and the epilogue at 0 -- the other workgroup of the
     // CU keeps the matrix pipe fed while this one does its SiLUs and stores (isolated: M1638400 N96 K864 346 -> 331 us,
     // M409600 N192 K1728 282 -> 279; in the bench 1945-1947 -> 1952-1963 frames/s); 2 = the reverse (no gain); 0 = off
-    const int prio = stagger >> 16;
+    const int prio = (stagger >> 16) & 15;
     if ((stagger & 0xffff) > 0) {
         const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4);   // HW_REG_HW_ID[19:16] = TG_ID
         if (hw_id & 1)
@@ -237,8 +252,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
         if (prio == 1) __builtin_amdgcn_s_setprio(1);
         if (prio == 2) __builtin_amdgcn_s_setprio(0);
         // ---- this tile and the next one -------------------------------------------------------------
-        const int vbn = vb + G;
-        const bool has_next = vbn < n_tiles;
+        const int vbn = vb + 1;
+        const bool has_next = tile_valid(vbn);
         int m0n = 0, n0n = 0;
         if (has_next) tile_m0n0(vbn, m0n, n0n);
         const int pl = m0 - W - 1 + lrow, pln = m0n - W - 1 + lrow;
@@ -919,7 +934,8 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     const int taps = a.Cin / 32 * 9;
     const int stagger = t.wgs_per_cu < 2 || grid <= ctx.num_cus ? 0 : stagger_env >= 0 ? stagger_env : (taps * 500 + 4095) / 4096;
     static const int prio_env = std::getenv("RMR_T32_PRIO") ? std::atoi(std::getenv("RMR_T32_PRIO")) : 1;
-    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, stagger | (prio_env << 16));
+    static const int walk_env = std::getenv("RMR_T32_WALK") ? std::atoi(std::getenv("RMR_T32_WALK")) : 0;   // 1: contiguous blocks (measured 1 % slower)
+    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, stagger | ((prio_env & 15) << 16) | ((walk_env & 1) << 20));
     RMR_HIP(hipGetLastError());
 }
 
