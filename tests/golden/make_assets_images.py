@@ -19,3 +19,9 @@ for i in range(10):
     im.save(path, quality=90)
     total += os.path.getsize(path)
 print("wrote", OUT, total, "bytes")
+# ... and ONE frame at its own size (2592 x 2048, re-encoded at quality 80: ~0.5 MB), so that configs[1] also runs once on a
+# reference frame at the reference's resolution and calibration (the letterbox of a 2592 x 2048 frame has the Q2 row quirk)
+im = Image.open(f"{REF}/0.jpg").convert("RGB")
+path = os.path.join(OUT, "full_0.jpg")
+im.save(path, quality=80)
+print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,8 +1,9 @@
 """BASELINE configs[1]-shaped run: the reference sample's call order (samples/sample_radar.h:106-127)
 at its calibration and frame size (samples/main.cpp:12-22: 2592 x 2048) on the reference's own sample
 clouds (tests/golden/assets_clouds.npz) plus a synthetic background cloud and injected robots,
-against the same order composed from the CPU oracles.  The sample JPEGs are not committed (15.9 MB
-each decoded); seeded structured frames of the same size stand in."""
+against the same order composed from the CPU oracles.  Seeded structured frames of the sample's size, the reference's
+ten sample JPEGs down-scaled 4x, and ONE of them at its own size (tests/golden/assets_images, made by
+tests/golden/make_assets_images.py)."""
 import os
 
 import numpy as np
@@ -32,6 +33,19 @@ def test_sample_radar_on_the_reference_sample_frames(tmp_path_factory, oracle):
     K = scenes.SAMPLE_K.copy()
     K[:2] *= 0.25
     _run_once_case(tmp_path_factory, oracle, frames, (648, 512), K, min_box=12)
+
+
+def test_sample_radar_on_a_reference_frame_at_its_own_size(tmp_path_factory, oracle):
+    """BASELINE configs[1] as specified: one of the reference's sample frames at ITS size (assets/images/0.jpg, 2592 x 2048,
+    committed re-encoded as tests/golden/assets_images/full_0.jpg) with its sample cloud and the calibration of
+    samples/main.cpp:12-22 unscaled, batch 1, the sample's call order.  A 2592 x 2048 frame is the letterbox case of
+    SURVEY Q2 (ratio 4.05: resized height 505, offsets for 506)."""
+    from rm_radar_amd import assets
+    gold = os.path.join(os.path.dirname(__file__), "golden", "assets_images")
+    frame = assets.read_image(os.path.join(gold, "full_0.jpg"))
+    assert frame.shape == (2048, 2592, 3) and frame.dtype == np.uint8
+    assert scenes.SAMPLE_SIZE == (2592, 2048)
+    _run_once_case(tmp_path_factory, oracle, [frame], scenes.SAMPLE_SIZE, scenes.SAMPLE_K)
 
 
 def _oracle_two_stage(oracle, img, car_head, p, armor_ref, cache, car_conf, armor_conf):
