@@ -850,6 +850,13 @@ const T32Tile kT32Tiles[] = {
     T32A(4, 2, 2, 3, 4, 4, 1, 1, 8),    // 24
     T32A(4, 2, 2, 3, 4, 4, 1, 1, 16),   // 25
     T32A(4, 2, 2, 3, 4, 4, 1, 1, 26),   // 26
+    // tile 3 (512 x 96, eight waves, ONE workgroup per CU: the weight slices are fetched once per 512 pixels)
+    T32A(8, 1, 2, 3, 10, 5, 0, 1, 2),   // no epilogue
+    T32A(8, 1, 2, 3, 10, 5, 0, 1, 8),   // DMAs out of range
+    T32A(8, 1, 2, 3, 10, 5, 0, 1, 10),  // neither
+    T32A(8, 1, 2, 3, 10, 5, 0, 1, 32),  // weight DMAs out of range
+    T32A(8, 1, 2, 3, 10, 5, 0, 1, 64),  // input DMAs out of range
+    T32A(8, 1, 2, 3, 10, 5, 0, 1, 26),  // MFMAs + barriers only
 #endif
 };
 constexpr int kNumT32Tiles = sizeof(kT32Tiles) / sizeof(kT32Tiles[0]);
