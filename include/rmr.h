@@ -389,7 +389,8 @@ rmr_status rmr_pipeline_run_streams(rmr_robot_detector* rd, rmr_locator* const* 
  * tables of rmr_pipeline_run_batch (mem = RMR_MEM_DEVICE) after rmr_upload_wait. */
 typedef struct rmr_upload rmr_upload;
 /* page-locked host memory (hipHostMalloc): a copy from it is one DMA, from pageable memory it is staged by the driver */
-rmr_status rmr_pinned_alloc(size_t bytes, void** out);
+rmr_status rmr_pinned_alloc(size_t bytes, void** out);   /* on the calling thread's current device */
+rmr_status rmr_pinned_alloc_on(int device, size_t bytes, void** out);
 void rmr_pinned_free(void* p);
 rmr_status rmr_upload_create(int device, int slots, size_t bytes_per_slot, rmr_upload** out);
 void rmr_upload_destroy(rmr_upload* up);

@@ -8,6 +8,13 @@ restates is the PUBLISHED algorithm: the Ultralytics YOLOv8 architecture (yolov8
 nn/modules: Conv = conv+BN+SiLU with BN folded, C2f, SPPF, Detect with DFL)
 as plain PyTorch fp32 functional ops on the CPU, reading the same weight pack the product loads.
 
+Independence from the product: the only thing taken from ``rm_radar_amd`` is the pack FILE READER
+(``weights.load_pack``: names -> arrays).  The layer plan is this module's own -- the depth / width / max-channel
+multiples of the published yolov8.yaml (``_ULTRALYTICS_SCALES``) -- and ``_check_against_ultralytics`` asserts that the
+tensors of the pack carry the Ultralytics module names with the shapes that plan implies (for scale "m" additionally
+against the literal channel counts of the published YOLOv8m: 48 / 96 / 192 / 384 / 576, repeats 2 / 4 / 4 / 2, head
+repeats 2), so a wrong table in the pack maker cannot agree with a wrong table here.
+
 ``emulate_f16=True`` rounds weights, the input and every stored activation to f16 exactly where
 the HIP engine stores f16 (f32 accumulate, f32 bias/SiLU/residual, one rounding per stored
 tensor; the two final 1x1 head convs stay f32), which isolates accumulation-order noise from
@@ -35,16 +42,64 @@ def _e4m3(t):
     return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
 
 
+# depth multiple, width multiple, max channels -- ultralytics/cfg/models/v8/yolov8.yaml `scales:`
+_ULTRALYTICS_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768), "l": (1.00, 1.00, 512),
+                       "x": (1.00, 1.25, 512)}
+
+
+def _plan(scale):
+    """Channels of P1..P5 and the C2f repeat counts of yolov8.yaml at a scale (parse_model: make_divisible(min(c, max) * w, 8),
+    n = max(round(n * d), 1))"""
+    depth, width, max_ch = _ULTRALYTICS_SCALES[scale]
+    ch = [int(-(-(min(c, max_ch) * width) // 8) * 8) for c in (64, 128, 256, 512, 1024)]
+    return {"ch": ch, "n": [max(round(r * depth), 1) for r in (3, 6, 6, 3)], "nh": max(round(3 * depth), 1)}
+
+
+def _check_against_ultralytics(tensors, scale, nc):
+    """The pack's tensors, by Ultralytics module name, must have the shapes of the published architecture."""
+    a = _plan(scale)
+    c1, c2, c3, c4, c5 = a["ch"]
+    if scale == "m":   # the literal published YOLOv8m
+        assert (a["ch"], a["n"], a["nh"]) == ([48, 96, 192, 384, 576], [2, 4, 4, 2], 2)
+    cb, cc = max(16, c3 // 4, 64), max(c3, min(nc, 100))   # Detect: c2 (box branch), c3 (class branch)
+    want = {"model.0.conv.weight": (c1, 3, 3, 3), "model.1.conv.weight": (c2, c1, 3, 3), "model.3.conv.weight": (c3, c2, 3, 3),
+            "model.5.conv.weight": (c4, c3, 3, 3), "model.7.conv.weight": (c5, c4, 3, 3),
+            "model.9.cv1.conv.weight": (c5 // 2, c5, 1, 1), "model.9.cv2.conv.weight": (c5, c5 * 2, 1, 1),
+            "model.16.conv.weight": (c3, c3, 3, 3), "model.19.conv.weight": (c4, c4, 3, 3)}
+    for name, cin, cout, n in (("model.2", c2, c2, a["n"][0]), ("model.4", c3, c3, a["n"][1]), ("model.6", c4, c4, a["n"][2]),
+                               ("model.8", c5, c5, a["n"][3]), ("model.12", c5 + c4, c4, a["nh"]), ("model.15", c4 + c3, c3, a["nh"]),
+                               ("model.18", c3 + c4, c4, a["nh"]), ("model.21", c4 + c5, c5, a["nh"])):
+        c = cout // 2
+        want[f"{name}.cv1.conv.weight"] = (2 * c, cin, 1, 1)
+        want[f"{name}.cv2.conv.weight"] = (cout, (2 + n) * c, 1, 1)
+        for i in range(n):
+            want[f"{name}.m.{i}.cv1.conv.weight"] = (c, c, 3, 3)
+            want[f"{name}.m.{i}.cv2.conv.weight"] = (c, c, 3, 3)
+        assert f"{name}.m.{n}.cv1.conv.weight" not in tensors, f"{name}: more bottlenecks than yolov8.yaml has at scale {scale}"
+    for i, cf in enumerate((c3, c4, c5)):
+        want[f"model.22.cv2.{i}.0.conv.weight"] = (cb, cf, 3, 3)
+        want[f"model.22.cv2.{i}.1.conv.weight"] = (cb, cb, 3, 3)
+        want[f"model.22.cv2.{i}.2.weight"] = (64, cb, 1, 1)
+        want[f"model.22.cv3.{i}.0.conv.weight"] = (cc, cf, 3, 3)
+        want[f"model.22.cv3.{i}.1.conv.weight"] = (cc, cc, 3, 3)
+        want[f"model.22.cv3.{i}.2.weight"] = (nc, cc, 1, 1)
+    for name, shape in want.items():
+        assert name in tensors, f"weight pack lacks {name}"
+        assert tuple(tensors[name].shape) == shape, f"{name}: pack has {tuple(tensors[name].shape)}, Ultralytics YOLOv8{scale} has {shape}"
+    n_conv = sum(1 for k in tensors if k.endswith(".weight"))
+    assert n_conv == len(want), f"pack has {n_conv} convolutions, the architecture {len(want)}"
+    return a
+
+
 class YoloV8Ref:
     def __init__(self, tensors, meta, emulate_f16=False, fp8=False):
-        from rm_radar_amd import weights as W  # layer-plan arithmetic only (numpy)
         self.meta = meta
         self.f16 = emulate_f16 or fp8
         self.fp8 = fp8
         import os
         self.fp8_head = os.environ.get("RMR_FP8_HEAD", "0") not in ("", "0")   # the engine's switch: Detect convs too
         emulate_f16 = self.f16
-        self.arch = W.arch(meta["scale"], meta["nc"])
+        self.arch = _check_against_ultralytics(tensors, meta["scale"], meta["nc"])   # this module's own plan, not the pack maker's
         self.nc = meta["nc"]
         self.t = {}
         for k, v in tensors.items():

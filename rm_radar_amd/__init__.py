@@ -655,11 +655,14 @@ class PinnedArray:
     """Page-locked host memory (rmr_pinned_alloc) as a numpy array: `.a`.  Copies from it to the GPU are single DMAs
     that really run asynchronously; a capture pipeline would write its frames straight into such buffers."""
 
-    def __init__(self, shape, dtype):
+    def __init__(self, shape, dtype, device=None):
         self.dtype = np.dtype(dtype)
         n = int(np.prod(shape)) * self.dtype.itemsize
         self._p = C.c_void_p()
-        check(lib().rmr_pinned_alloc(max(n, 1), C.byref(self._p)))
+        if device is None:   # the calling thread's current device
+            check(lib().rmr_pinned_alloc(max(n, 1), C.byref(self._p)))
+        else:                # the device whose upload ring will read it (one rank per GPU: never GPU 0 by default)
+            check(lib().rmr_pinned_alloc_on(int(device), max(n, 1), C.byref(self._p)))
         self.a = np.frombuffer((C.c_char * max(n, 1)).from_address(self._p.value), dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
 
     def close(self):
@@ -959,11 +962,21 @@ class profile:
         check(lib().rmr_profile_enable(self.device, 0))
         return False
 
-    def read(self):
+    def read(self, by_stage=False):
+        """{name: {launches, total_ms, flops, bytes}}.  Launches enqueued by a RobotDetector carry their stage in the name
+        ("car|conv n64 ...", "armor|conv n256 ..."); by_stage=False (default) merges the stages under the bare name."""
         n = C.c_int()
         check(lib().rmr_profile_read(self.device, None, 0, C.byref(n)))
         arr = (_lib.KernelStat * max(n.value, 1))()
         check(lib().rmr_profile_read(self.device, arr, n.value, C.byref(n)))
-        return {arr[i].name.decode(): {"launches": arr[i].launches, "total_ms": arr[i].total_ms,
-                                       "flops": arr[i].flops, "bytes": arr[i].bytes}
-                for i in range(n.value)}
+        out = {}
+        for i in range(n.value):
+            name = arr[i].name.decode()
+            if not by_stage and "|" in name:
+                name = name.split("|", 1)[1]
+            e = out.setdefault(name, {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            e["launches"] += arr[i].launches
+            e["total_ms"] += arr[i].total_ms
+            e["flops"] += arr[i].flops
+            e["bytes"] += arr[i].bytes
+        return out

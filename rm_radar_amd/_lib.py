@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "librmr.so")
+# RMR_LIB: another build of the same library (tools/experiments: `make EXPERIMENTS=1` writes _build_exp/librmr.so)
+LIB_PATH = os.environ.get("RMR_LIB") or os.path.join(_HERE, "_build", "librmr.so")
 
 OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_LOGIC, ERR_DEVICE, ERR_CAPACITY = range(6)
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -159,6 +160,7 @@ SYMBOLS = {
     "rmr_robot_detector_detect_batch": (C.c_int, [_vp, _P(Image), C.c_int, _ip, C.c_int,
                                                   _P(Robot), _ip, C.c_int]),
     "rmr_pinned_alloc": (C.c_int, [C.c_size_t, _P(_vp)]),
+    "rmr_pinned_alloc_on": (C.c_int, [C.c_int, C.c_size_t, _P(_vp)]),
     "rmr_pinned_free": (None, [_vp]),
     "rmr_upload_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, _P(_vp)]),
     "rmr_upload_destroy": (None, [_vp]),

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -77,10 +78,12 @@ struct rmr_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     DevBuf<unsigned char> send, recv;
-    // FILE: every file of a communicator carries its EPOCH (the number of communicators this rank has created on the
-    // directory before, a collective count: all ranks create communicators in the same order), so a second
-    // communicator on a directory -- a rank restarted after a crash, a caller-supplied path -- can never read a
-    // record file an earlier one left behind
+    // FILE: every file of a communicator carries its EPOCH, so a second communicator on a directory -- a rank restarted
+    // after a crash, a caller-supplied path -- can never read a record file an earlier one left behind.  The epoch is a
+    // COLLECTIVE value (round 4; before, every rank derived it from its own surviving markers and two ranks could
+    // disagree after a clean close or a crash): rank 0 picks 1 + the highest epoch of ANY file still in the directory
+    // and hands it to every other rank in a token handshake (agree_on_epoch), which makes creation a collective call
+    // like ncclCommInitRank.
     std::string dir;
     long long epoch = 0, seq = 0;
     bool joined = false;   // the session marker is written: the leave protocol applies
@@ -99,6 +102,71 @@ struct rmr_comm {
         return true;
     }
     static void touch(const std::string& path) { std::ofstream f(path, std::ios::binary | std::ios::trunc); }
+    static bool publish(const std::string& path, const std::string& text) {   // readers never see a partial file
+        const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+        {
+            std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+            f << text;
+            if (!f) return false;
+        }
+        return std::rename(tmp.c_str(), path.c_str()) == 0;
+    }
+    static std::string slurp(const std::string& path) {
+        std::ifstream f(path, std::ios::binary);
+        std::string t;
+        if (f) std::getline(f, t);
+        return t;
+    }
+    // Rank r != 0 publishes hello.<r> = a fresh token and waits for welcome.<r> = "<token> <epoch>" carrying ITS token
+    // (a welcome left by an earlier communicator, or one answering a hello a crashed process left, has another token and
+    // is ignored).  Rank 0 picks the epoch, then keeps answering whatever token each hello currently holds until that
+    // rank's session marker of the new epoch appears (the caller writes it right after this returns).
+    static long long agree_on_epoch(const std::string& dir, int rank, int world) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto late = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120); };
+        if (rank != 0) {
+            std::random_device rd;
+            const std::string token = std::to_string(((unsigned long long)rd() << 32) ^ rd() ^ ((unsigned long long)getpid() << 20) ^
+                                                     (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+            const std::string hello = dir + "/hello." + std::to_string(rank), welcome = dir + "/welcome." + std::to_string(rank);
+            if (!publish(hello, token)) fail(RMR_ERR_RUNTIME, "rmr_comm_create: cannot write into '%s'", dir.c_str());
+            for (;;) {
+                const std::string w = slurp(welcome);
+                const size_t sp = w.find(' ');
+                if (sp != std::string::npos && w.compare(0, sp, token) == 0) {
+                    std::remove(hello.c_str());
+                    std::remove(welcome.c_str());
+                    return std::atoll(w.c_str() + sp + 1);
+                }
+                if (late()) fail(RMR_ERR_RUNTIME, "rmr_comm_create: rank 0 did not answer in '%s' within 120 s", dir.c_str());
+                std::this_thread::sleep_for(std::chrono::microseconds(300));
+            }
+        }
+        long long last = -1;
+        if (DIR* d = opendir(dir.c_str())) {
+            while (const dirent* e = readdir(d)) {
+                const char* n = e->d_name;
+                if (n[0] == 'e' && n[1] >= '0' && n[1] <= '9') last = std::max(last, std::atoll(n + 1));
+            }
+            closedir(d);
+        }
+        const long long epoch = last + 1;
+        std::vector<std::string> welcomed(world);
+        for (int pending = world - 1; pending > 0;) {
+            pending = 0;
+            for (int r = 1; r < world; ++r) {
+                struct stat st;
+                if (stat((dir + "/e" + std::to_string(epoch) + ".session." + std::to_string(r)).c_str(), &st) == 0) continue;
+                ++pending;
+                const std::string token = slurp(dir + "/hello." + std::to_string(r));
+                if (!token.empty() && token != welcomed[r] && publish(dir + "/welcome." + std::to_string(r), token + " " + std::to_string(epoch)))
+                    welcomed[r] = token;
+            }
+            if (pending && late()) fail(RMR_ERR_RUNTIME, "rmr_comm_create: not every rank joined '%s' within 120 s", dir.c_str());
+            if (pending) std::this_thread::sleep_for(std::chrono::microseconds(300));
+        }
+        return epoch;
+    }
     // Leaving: a peer may still be reading this rank's last record files, so a rank first says it will read no more
     // ("done"), removes its own files once every rank has said so, and says "gone"; rank 0 waits for that and sweeps
     // the markers (and the directory, when rmr_comm_unique_id made it).  A peer that never arrives (crashed) costs a
@@ -178,19 +246,10 @@ rmr_status rmr_comm_create(int transport, int device, int rank, int world, const
             struct stat st;
             if (c->dir.empty() || stat(c->dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: '%s' is not a directory", c->dir.c_str());
-            // epoch = 1 + the highest session marker this rank has left on the directory
-            const std::string tail = ".session." + std::to_string(rank);
-            long long last = -1;
-            if (DIR* d = opendir(c->dir.c_str())) {
-                while (const dirent* e = readdir(d)) {
-                    const std::string n = e->d_name;
-                    if (n.size() > tail.size() + 1 && n[0] == 'e' && n.compare(n.size() - tail.size(), tail.size(), tail) == 0)
-                        last = std::max(last, std::atoll(n.c_str() + 1));
-                }
-                closedir(d);
-            }
-            c->epoch = last + 1;
-            rmr_comm::touch(c->file("session", -1, rank));
+            c->epoch = rmr_comm::agree_on_epoch(c->dir, rank, world);
+            rmr_comm::touch(c->file("session", -1, rank));   // for ranks != 0 this is also the ack rank 0 waits for
+            if (rank == 0 && !c->wait_all("session", 120.0))
+                fail(RMR_ERR_RUNTIME, "rmr_comm_create: not every rank joined '%s' within 120 s", c->dir.c_str());
             c->joined = true;
         } else {
             fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: unknown transport %d", transport);

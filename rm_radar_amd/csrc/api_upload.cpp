@@ -33,12 +33,20 @@ struct rmr_upload {
 
 extern "C" {
 
-rmr_status rmr_pinned_alloc(size_t bytes, void** out) {
+rmr_status rmr_pinned_alloc_on(int device, size_t bytes, void** out) {
     return guarded([&] {
         if (!out || bytes == 0) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_pinned_alloc: bad arguments");
-        (void)device_ctx(0);  // fails loudly without a GPU
-        RMR_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+        // page-locked under the context of the device whose upload ring will read it (a rank of a multi-GPU host must
+        // not open a context on GPU 0 for this), and portable: visible to every device context of the process
+        device_ctx(device).use();  // fails loudly without a GPU
+        RMR_HIP(hipHostMalloc(out, bytes, hipHostMallocPortable));
     });
+}
+
+rmr_status rmr_pinned_alloc(size_t bytes, void** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;   // the calling thread's current device
+    return rmr_pinned_alloc_on(dev, bytes, out);
 }
 
 void rmr_pinned_free(void* p) {

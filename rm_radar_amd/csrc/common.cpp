@@ -1,6 +1,7 @@
 // common.cpp -- error slot, per-device context, HIP-event profiler.
 #include "common.h"
 
+#include <cstdlib>
 #include <memory>
 
 namespace rmr {
@@ -11,6 +12,8 @@ void set_last_error(const std::string& s) { g_last_error = s; }
 const std::string& last_error() { return g_last_error; }
 
 // ---- Profiler ---------------------------------------------------------------------
+thread_local int Profiler::stage = 0;
+
 hipEvent_t Profiler::get_event() {
     std::lock_guard<std::mutex> lk(mu);
     if (!pool.empty()) {
@@ -26,6 +29,14 @@ hipEvent_t Profiler::get_event() {
 void Profiler::push(const Pending& p) {
     std::lock_guard<std::mutex> lk(mu);
     pending.push_back(p);
+    if (!order_checked) {
+        order_checked = true;
+        if (const char* f = std::getenv("RMR_PROFILE_ORDER")) order_log = *f ? std::fopen(f, "a") : nullptr;
+    }
+    if (order_log) {
+        std::fprintf(order_log, "%d %s|%s|%.0f|%.0f\n", on, p.stage == 1 ? "car" : p.stage == 2 ? "armor" : "", p.name, p.flops, p.bytes);
+        std::fflush(order_log);
+    }
 }
 
 void Profiler::resolve() {
@@ -34,7 +45,7 @@ void Profiler::resolve() {
         (void)hipEventSynchronize(p.b);
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            ProfEntry& e = stats[p.name];
+            ProfEntry& e = stats[p.stage == 1 ? std::string("car|") + p.name : p.stage == 2 ? std::string("armor|") + p.name : std::string(p.name)];
             e.launches += 1;
             e.total_ms += ms;
             e.flops += p.flops;
@@ -58,6 +69,7 @@ Profiler::~Profiler() {
         (void)hipEventDestroy(p.b);
     }
     for (auto e : pool) (void)hipEventDestroy(e);
+    if (order_log) std::fclose(order_log);
 }
 
 // ---- DeviceCtx ----------------------------------------------------------------------

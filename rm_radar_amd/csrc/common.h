@@ -126,11 +126,22 @@ struct ProfEntry {
 
 struct Profiler {
     int on = 0;  // 0 off, 1 every launch, 2 only launches that declare FLOPs (the convolution family)
+    // which network stage the launches being enqueued belong to (set by RobotDetector around its two detect calls: 1 = car,
+    // 2 = armor; 0 = a lone Detector): the stat name gets the prefix "car|" / "armor|", so a step whose two stages launch
+    // the same shapes (batch 256: car chunk = armor chunk) can still be told apart.  Thread-local: the locate helper
+    // thread's launches are never tagged.
+    static thread_local int stage;
+    // RMR_PROFILE_ORDER=<file> (read once): every profiled launch is also appended to that file in enqueue order
+    // ("<level> <stage>|<name>|<flops>|<bytes>"), so that tools/pmc_traffic.py can give the k-th convolution dispatch of a
+    // rocprofv3 --pmc pass its layer (PMC rows carry kernel symbols only)
+    FILE* order_log = nullptr;
+    bool order_checked = false;
     std::mutex mu;
     struct Pending {
         hipEvent_t a, b;
         const char* name;
         double flops, bytes;
+        int stage;
     };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -151,7 +162,7 @@ struct ProfScope {
     ProfScope(Profiler& prof, hipStream_t stream, const char* name, double flops = 0, double bytes = 0)
         : p(prof.on == 1 || (prof.on == 2 && flops > 0) ? &prof : nullptr), s(stream) {
         if (p) {
-            rec = Profiler::Pending{p->get_event(), p->get_event(), name, flops, bytes};
+            rec = Profiler::Pending{p->get_event(), p->get_event(), name, flops, bytes, Profiler::stage};
             (void)hipEventRecord(rec.a, s);
         }
     }

@@ -141,13 +141,21 @@ int conv_g32_num_tiles();
 ConvTile conv_g32_tile(int id);
 bool conv_g32_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_g32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
-// 3x3 / stride-1 layers through Winograd F(2, 3) along x on the conv_t32 skeleton (conv_w1d.hip): 1.5x fewer MFMAs, the
-// input transform in LDS, the transformed weights pre-packed (a.wt_w1d); even map widths, Cin % 32 == 0
+// 3x3 / stride-1 layers through Winograd F(2, 3) along x on the conv_t32 skeleton: a measured experiment of round 3 (slower
+// than conv_t32 on every layer, DESIGN.md "Round 3"), NOT part of the product library: tools/experiments/conv_w1d.hip is
+// compiled in by `make EXPERIMENTS=1` only; the default build has no such tiles (ids 980.. are rejected)
+#ifdef RMR_EXPERIMENTS
 int conv_w1d_num_tiles();
 ConvTile conv_w1d_tile(int id);
 bool conv_w1d_supported(const ConvArgs& a, int tile);  // tile < 0: any
 void launch_conv_w1d(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
 void pack_conv_weights_w1d(const __half* packed, int cout_pad, int cin, int Kp, std::vector<__half>& out);
+#else
+inline int conv_w1d_num_tiles() { return 0; }
+inline bool conv_w1d_supported(const ConvArgs&, int) { return false; }
+inline void launch_conv_w1d(DeviceCtx&, hipStream_t, ConvArgs, int) {}
+inline void pack_conv_weights_w1d(const __half*, int, int, int, std::vector<__half>& out) { out.assign(8, __half()); }
+#endif
 // the fp8 form (conv_t32f8.hip): e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4, f16 output
 int conv_t32f8_num_tiles();
 ConvTile conv_t32f8_tile(int id);

@@ -100,23 +100,15 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     const int split = a.split > 1 ? a.split : 1;
     int zsplit = 0, tile_id = 0;
     // The walk (vb = this workgroup's k-th tile): the tiles of an XCD are a contiguous range of logical ids; a workgroup takes
-    // every (G / 8)-th tile of that range (the default), or (RMR_T32_WALK=1, an experiment of round 3) a CONTIGUOUS block of
-    // it, so that its consecutive tiles are the channel tiles of one pixel range and the neighbouring ranges, whose input
-    // rows it has just pulled into its XCD's L2.  Why it was tried -- -DRMR_T32_ABLATE on M1638400 N96 K864, tile 10: full 368
-    // us, input DMAs out of range 257, weight DMAs out of range 304, all DMAs out of range (instructions still issued) 232,
-    // no counted waits 368, and without epilogue AND DMA data 187 = the MFMAs alone (197): what the K loop loses is the DATA
-    // PATH of the LDS-DMAs (the input's 64-byte segments most of all), not their issue and not the waits.  What it gave:
-    // 308 -> 302 us on M409600 N192 K1728, 355 -> 359 on the 96-channel layer, 1887-1891 -> 1869-1871 frames/s in the bench
-    // (neighbouring tiles already run side by side on neighbouring workgroups of one XCD and share the L2 fill).
-    const bool walk_contig = (stagger >> 20) & 1;
+    // every (G / 8)-th tile of that range.  (Round 3 also tried CONTIGUOUS blocks per workgroup, so that a workgroup's next
+    // tile reads rows its XCD's L2 already holds: -2 % / +1 % on the two main layers, -1 % frames/s -- neighbouring tiles
+    // already run side by side on one XCD and share the L2 fill; DESIGN.md "Round 3".  Removed in round 4.)
     const int my_xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, Gx = G >> 3;
     const int cnt_x = q8 + (my_xcd < r8 ? 1 : 0);
     const int base_x = my_xcd < r8 ? my_xcd * (q8 + 1) : r8 * (q8 + 1) + (my_xcd - r8) * q8;
-    const int per_lo = cnt_x / Gx, per_rem = cnt_x - per_lo * Gx;
-    const int my_first = jx * per_lo + min(jx, per_rem), my_cnt = per_lo + (jx < per_rem ? 1 : 0);
-    const auto tile_valid = [&](int k) { return walk_contig ? k < my_cnt : jx + k * Gx < cnt_x; };
+    const auto tile_valid = [&](int k) { return jx + k * Gx < cnt_x; };
     const auto tile_m0n0 = [&](int k, int& m0, int& n0) {
-        const int lid = base_x + (walk_contig ? my_first + k : jx + k * Gx);
+        const int lid = base_x + jx + k * Gx;
         tile_id = lid / split;
         zsplit = lid - tile_id * split;
         m0 = (tile_id / nt_count) * BM;
@@ -498,286 +490,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
 
 
 #ifdef RMR_T32_PINGPONG
-// ---- the ping-pong form (round 3; development builds only: measured 1.9x SLOWER, DESIGN.md "Round 3") --------------------
-// -DRMR_T32_ABLATE on the kernel above (M1638400 N96 K864, tile 10): MFMAs + barriers alone 170 us, everything else alone
-// 250 us (173 without the epilogue), together 354: the two streams of a wave do not overlap.  Here the eight waves are two
-// groups of four -- waves w and w + 4 share a SIMD (tools/microbench/wave_simd.hip) -- that ALTERNATE roles, as the 8-wave
-// attention loop of the guide does:
-//
-//     time      2t                                2t + 1
-//     group A   M_t: the 2 NM MFMAs of tap t      F: DMA slots of tap t, wait, fragments of tap t + 1 (both K-steps)
-//     group B   F: DMA slots of tap t, wait,      M_t
-//               fragments of tap t
-//
-// with one s_barrier between the segments.  Ring, counted waits and stream logic are conv_t32's (a slice is issued R - 1
-// taps ahead of its tap in both groups and waited for R - 3 taps later; its slot's last readers finished two segments
-// before), the fragments of a tap are single-buffered (the same 40 registers).  Bit-exact (it passed conv_t32's tests as
-// tiles 13..18) and 534 us against 282 on M409600 N192 K1728: MFMA segments alone 307, filler segments alone 191.
-template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv_t32pp_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
-    constexpr int NW = WM * WN;
-    static_assert(NW == 8, "two groups of four waves: waves w and w + 4 share a SIMD");
-    constexpr int BM = WM * MREP * 32;
-    constexpr int BN = WN * NREP * 32;
-    constexpr int NB = BN / 16;
-    constexpr int SLOTS = NB + A_SLOTS;
-    constexpr int D = (SLOTS + NW - 1) / NW;
-    constexpr int SLOT_BYTES = BN * 64;
-    constexpr int ATAPS = 11 - R;
-    constexpr unsigned OOB = 0xffff0000u;
-    static_assert(R >= 4 && R <= 10, "ring depth");
-    static_assert((R - 3) * D <= 63, "vmcnt is 6 bits");
-    static_assert(EPI == 0, "lane-pair stores");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-    const unsigned lds0 = sgpr((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
-    const int a_buf_bytes = a_rows * 64;
-    const int ring_base = 2 * a_buf_bytes;
-    const int zero_off = ring_base + R * SLOT_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                  // 0: matrix segment first
-    const int wm = wave / WN, wn = wave % WN;
-    const int bias_off = zero_off + 1024;
-
-    const int nt_count = a.Cout_pad / BN;
-    const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
-    const int G = gridDim.x;
-    const auto tile_m0n0 = [&](int vb, int& m0, int& n0) {
-        const int xcd = vb & 7;
-        const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
-        m0 = (lid / nt_count) * BM;
-        n0 = (lid % nt_count) * BN;
-    };
-    int vb = blockIdx.x;
-    if (vb >= n_tiles) return;
-    int m0, n0;
-    tile_m0n0(vb, m0, n0);
-    const int W = a.W;
-    const int npix = a.M;
-
-    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu), sgpr(a.in_bytes), sgpr(0x00020000u)};
-    const u32x4 wt_rsrc = {sgpr((unsigned)(size_t)a.wt_t32), sgpr((unsigned)((size_t)a.wt_t32 >> 32) & 0xffffu), sgpr(a.wt_t32_bytes),
-                           sgpr(0x00020000u)};
-
-    const int lrow = lane >> 2;
-    const int lch = (lane & 3) ^ ((lrow >> 2) & 3);
-    const unsigned cs2 = (unsigned)a.in_cs * 2u;
-    const unsigned in_cb = (unsigned)((a.in_co + lch * 8) * 2);
-    const unsigned lane16 = (unsigned)lane * 16u;
-    const int na = a_rows / 16;
-    const int chunks = a.Cin / 32;
-    const int total = chunks * 9;
-    const unsigned wstep = (unsigned)(a.Cout_pad / 16) * 1024u;
-    const unsigned scratch = sgpr(lds0 + zero_off);
-
-    if (tid < 4) *(u32x4*)(smem + zero_off + tid * 16) = u32x4{0, 0, 0, 0};
-    for (int i = tid; i < a.Cout_pad; i += NW * 64) *(float*)(smem + bias_off + i * 4) = a.bias[i];
-
-    const auto in_off = [&](int lo_l, int ia, int cc) {
-        const int p = min(max(lo_l + ia * 16, 0), npix - 1);
-        return __umul24((unsigned)p, cs2) + in_cb + (unsigned)cc * 64u;
-    };
-
-    bool s_isw[D];
-    u32x4 s_rsrc[D];
-    unsigned s_wdst[D], s_wsrc[D];
-    int s_aidx[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        const int q = wave + NW * j;
-        s_isw[j] = q < NB;
-        s_rsrc[j] = NW * (j + 1) <= NB ? wt_rsrc : NW * j >= NB ? in_rsrc : (s_isw[j] ? wt_rsrc : in_rsrc);
-        s_wdst[j] = lds0 + ring_base + q * 1024;
-        s_wsrc[j] = (unsigned)q * 1024u;
-        s_aidx[j] = q - NB;
-    }
-
-    {
-        const int pl0 = m0 - W - 1 + lrow;
-        for (int ia = wave; ia < na; ia += NW) dma16s(in_rsrc, sgpr(lds0 + ia * 1024), in_off(pl0, ia, 0), 0u);
-#pragma unroll
-        for (int s = 0; s < R - 1; ++s)
-            for (int q = wave; q < NB; q += NW)
-                dma16s(wt_rsrc, sgpr(lds0 + ring_base + s * SLOT_BYTES + q * 1024), s < total ? lane16 : OOB,
-                       sgpr((unsigned)s * wstep + (unsigned)(n0 / 16 + q) * 1024u));
-    }
-
-    const int fr = lane & 31, kq = lane >> 5;
-    const int a_row0 = wm * MREP * 32 + fr + W + 1;
-    int zsel[MREP];
-#pragma unroll
-    for (int i = 0; i < MREP; ++i) zsel[i] = zero_off - i * 2048;
-    const int wlane = ring_base + (wn * NREP * 32 + fr) * 64 + ((kq ^ ((fr >> 2) & 3)) << 4);
-    const auto lds16 = [&](int off) { return *(const half8*)(smem + off); };
-    const auto a_addr = [&](int abuf, int t) {
-        const int row = a_row0 + (t / 3 - 1) * W + (t % 3 - 1);
-        return abuf + row * 64 + ((kq ^ ((row >> 2) & 3)) << 4);
-    };
-
-    wait_vm<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    constexpr int NM = MREP * NREP;
-    int slot = 0;                     // ring slot of the tap whose DMA segment comes next
-    int abuf = 0;
-    unsigned gw = R - 1;
-    unsigned gwoff = (unsigned)(R - 1) * wstep;
-    unsigned w_tile = (unsigned)(n0 / 16) * 1024u;
-    unsigned w_live = 1u;
-
-    for (;;) {
-        const int vbn = vb + G;
-        const bool has_next = vbn < n_tiles;
-        int m0n = 0, n0n = 0;
-        if (has_next) tile_m0n0(vbn, m0n, n0n);
-        const int pl = m0 - W - 1 + lrow, pln = m0n - W - 1 + lrow;
-        const unsigned w_tile_next = (unsigned)(n0n / 16) * 1024u;
-        bool up[MREP], dn[MREP], lf[MREP], rt[MREP];
-#pragma unroll
-        for (int i = 0; i < MREP; ++i) {
-            const int m = m0 + (wm * MREP + i) * 32 + fr;
-            const int x = m % W, y = (m / W) % a.H;
-            up[i] = y > 0;
-            dn[i] = y < a.H - 1;
-            lf[i] = x > 0;
-            rt[i] = x < W - 1;
-        }
-        floatx16 acc[MREP][NREP];
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
-#pragma unroll
-            for (int j = 0; j < NREP; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        half8 xa[MREP], wa[NREP], xb[MREP], wb[NREP];
-        // both K-steps' fragments of tap `tr` (a constant) from input buffer ab and ring slot sl
-        const auto reads = [&](auto Tr, int ab, int sl) {
-            constexpr int tr = decltype(Tr)::value;
-            constexpr int dy = tr / 3 - 1, dx = tr % 3 - 1;
-            const int at = a_addr(ab, tr);
-            const int wr = wlane + sl * SLOT_BYTES;
-#pragma unroll
-            for (int i = 0; i < MREP; ++i) {
-                const bool v = (dy < 0 ? up[i] : dy > 0 ? dn[i] : true) && (dx < 0 ? lf[i] : dx > 0 ? rt[i] : true);
-                const int sel = v ? at : zsel[i];
-                xa[i] = lds16(sel + i * 2048);
-                xb[i] = lds16((sel ^ 32) + i * 2048);
-            }
-#pragma unroll
-            for (int j = 0; j < NREP; ++j) {
-                wa[j] = lds16(wr + j * 2048);
-                wb[j] = lds16((wr ^ 32) + j * 2048);
-            }
-        };
-        // the matrix segment of a tap: 2 NM MFMAs on the fragments in registers
-        const auto seg_m = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, NM>([&](auto Kc) {
-                constexpr int k = decltype(Kc)::value;
-                acc[k / NREP][k % NREP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[k % NREP], xa[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
-            });
-            static_for<0, NM>([&](auto Kc) {
-                constexpr int k = decltype(Kc)::value;
-                acc[k / NREP][k % NREP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[k % NREP], xb[k / NREP], acc[k / NREP][k % NREP], 0, 0, 0);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        };
-
-        for (int cc = 0; cc < chunks; ++cc) {
-            const int abuf_next = a_buf_bytes - abuf;
-            const bool in_tile = cc + 1 < chunks;
-            const bool a_live = in_tile || has_next;
-            const int a_pl = in_tile ? pl : pln;
-            const int a_cc = in_tile ? cc + 1 : 0;
-            // the filler segment of tap t: the fragments of the tap this wave computes next (tap t for group B, AHEAD = 0;
-            // tap t + 1 for group A, AHEAD = 1), the D DMA slots of tap t, the counted wait, the stream's advance
-            const auto seg_f = [&](auto T, auto Ahead) {
-                constexpr int t = decltype(T)::value;
-                constexpr int AHEAD = decltype(Ahead)::value;
-                constexpr int tr = (t + AHEAD) % 9;
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    const int sl = AHEAD ? (slot + 1 == R ? 0 : slot + 1) : slot;
-                    reads(tap_c<tr>{}, (AHEAD && t == 8) ? abuf_next : abuf, sl);
-                }
-                const int slot_w = slot == 0 ? R - 1 : slot - 1;
-                const unsigned wv = w_live ? lane16 : OOB;
-                static_for<0, D>([&](auto Dc) {
-                    constexpr int d = decltype(Dc)::value;
-                    constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
-                    constexpr bool a_tap = t < ATAPS;
-                    const unsigned w_lds = s_wdst[d] + slot_w * SLOT_BYTES, w_soff = s_wsrc[d] + w_tile + gwoff;
-                    const int ia = t * A_SLOTS + s_aidx[d];
-                    const bool alive = a_tap && a_live && ia < na && s_aidx[d] < A_SLOTS;
-                    const unsigned a_lds = alive ? lds0 + abuf_next + ia * 1024 : scratch;
-                    if constexpr (all_w) {
-                        dma16s(wt_rsrc, sgpr(w_lds), wv, sgpr(w_soff));
-                    } else if constexpr (all_a) {
-                        if constexpr (a_tap) {
-                            unsigned av = in_off(a_pl, ia, a_cc);
-                            asm volatile("" : "+v"(av));
-                            dma16s(in_rsrc, sgpr(a_lds), alive ? av : OOB, 0u);
-                        }
-                    } else {
-                        const bool isw = s_isw[d];
-                        unsigned av = in_off(a_pl, ia, a_cc);
-                        asm volatile("" : "+v"(av));
-                        av = (a_tap && alive) ? av : OOB;
-                        dma16s(s_rsrc[d], sgpr(isw ? w_lds : a_lds), isw ? wv : av, sgpr(isw ? w_soff : 0u));
-                    }
-                });
-                constexpr int pending = [] {
-                    int n = 0;
-                    for (int k = 0; k < R - 3; ++k) {
-                        const int tt = (t - k + 9) % 9;
-                        for (int j = 0; j < D; ++j) n += (NW * j >= NB && tt >= ATAPS) ? 0 : 1;
-                    }
-                    return n;
-                }();
-                wait_vm<pending>();
-                const unsigned wrap = 0u - (unsigned)(gw + 1 == (unsigned)total);
-                gw = (gw + 1) & ~wrap;
-                gwoff = (gwoff + wstep) & ~wrap;
-                w_tile ^= (w_tile ^ w_tile_next) & wrap;
-                w_live ^= (w_live ^ (unsigned)has_next) & wrap;
-                slot = slot + 1 == R ? 0 : slot + 1;
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            if (grp == 0) {
-                if (cc == 0) reads(tap_c<0>{}, abuf, slot);   // a tile's first tap (the next tile's masks were not known one segment ago)
-                static_for<0, 9>([&](auto T) {
-                    seg_m();
-                    __builtin_amdgcn_s_barrier();
-                    seg_f(T, tap_c<1>{});
-                    __builtin_amdgcn_s_barrier();
-                });
-            } else {
-                static_for<0, 9>([&](auto T) {
-                    seg_f(T, tap_c<0>{});
-                    __builtin_amdgcn_s_barrier();
-                    seg_m();
-                    __builtin_amdgcn_s_barrier();
-                });
-            }
-            abuf = abuf_next;
-        }
-
-        epilogue<MREP, NREP, EPI, true, (NREP < 4 && MREP * NREP <= 8)>(a, acc, smem, 0, bias_off, m0, n0, wm, wn, lane);
-
-        if (!has_next) break;
-        vb = vbn;
-        m0 = m0n;
-        n0 = n0n;
-    }
-    wait_vm<0>();
-}
-#endif  // RMR_T32_PINGPONG
+#include "../../tools/experiments/conv_t32_pingpong.inc"
+#endif
 
 struct T32Tile {
     int bm, bn, threads, a_slots, ring, nrep, epi, wgs_per_cu;
@@ -941,8 +655,7 @@ void launch_conv_t32(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile) {
     const int taps = a.Cin / 32 * 9;
     const int stagger = t.wgs_per_cu < 2 || grid <= ctx.num_cus ? 0 : stagger_env >= 0 ? stagger_env : (taps * 500 + 4095) / 4096;
     static const int prio_env = std::getenv("RMR_T32_PRIO") ? std::atoi(std::getenv("RMR_T32_PRIO")) : 1;
-    static const int walk_env = std::getenv("RMR_T32_WALK") ? std::atoi(std::getenv("RMR_T32_WALK")) : 0;   // 1: contiguous blocks (measured 1 % slower)
-    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, stagger | ((prio_env & 15) << 16) | ((walk_env & 1) << 20));
+    t.kernel<<<grid, t.threads, lds, stream>>>(a, rows, n_tiles, stagger | ((prio_env & 15) << 16));
     RMR_HIP(hipGetLastError());
 }
 

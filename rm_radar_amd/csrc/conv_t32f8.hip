@@ -628,6 +628,7 @@ void launch_conv_t32f8(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile)
     if (a.in8_cs % 64 || a.out_cs % 4 || a.out_co % 4) fail(RMR_ERR_LOGIC, "conv_t32f8: misaligned view");
     if (a.out8 && (a.out32 || ((a.out_cs | a.out_co) & 7) || a.out8_cs % 16))
         fail(RMR_ERR_LOGIC, "conv_t32f8: the e4m3 copy of the output needs an f16 output in 8-channel alignment");
+    if (a.out8_only && (a.res || !a.out8)) fail(RMR_ERR_LOGIC, "conv_t32f8: an e4m3-only output cannot carry a shortcut (the planner keeps the f16 copy there)");
     if (a.in8_bytes == 0 || a.in8_bytes > 0xf0000000ull || a.wt8_bytes == 0)
         fail(RMR_ERR_LOGIC, "conv_t32f8: buffer sizes not set or input view larger than 3.75 GiB");
     static std::once_flag once;

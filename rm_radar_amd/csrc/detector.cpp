@@ -124,7 +124,10 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
 void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out) {
     const int n = (int)descs.size();
     out.assign(n, {});
-    if (n == 0) return;  // Q10d: the reference would abort on an empty batch; return nothing
+    if (n == 0) {        // Q10d: the reference would abort on an empty batch; return nothing --
+        last_n_ = 0;     // and read_heads() must not hand out the previous call's heads as this call's
+        return;
+    }
     enqueue(descs, true);
     RMR_HIP(hipStreamSynchronize(stream_));
     bool extra = false;
@@ -257,7 +260,14 @@ void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int*
     std::vector<LetterboxDesc> descs;
     fill_descs(frames, nullptr, descs);
     std::vector<std::vector<rmr_detection>> cars;
-    car_->detect_staged(descs, cars);
+    struct StageTag {   // profile names of the launches enqueued meanwhile: "car|..." / "armor|..."
+        explicit StageTag(int s) { Profiler::stage = s; }
+        ~StageTag() { Profiler::stage = 0; }
+    };
+    {
+        StageTag tag(1);
+        car_->detect_staged(descs, cars);
+    }
 
     if (forced_crops) {
         // throughput benches with synthetic weights: the car stage ran in full, but the crops
@@ -298,7 +308,10 @@ void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int*
         }
     }
     std::vector<std::vector<rmr_detection>> armors;
-    armor_->detect_staged(descs, armors);
+    {
+        StageTag tag(2);
+        armor_->detect_staged(descs, armors);
+    }
 
     // Robot assembly + per-label de-duplication (detector.cpp:427-454)
     size_t k = 0;

@@ -164,7 +164,7 @@ void Yolov8::upload_t32(ConvW& cw, const std::vector<__half>& packed) {
     RMR_HIP(hipMemcpy(cw.w32.p, p32.data(), p32.size() * sizeof(__half), hipMemcpyHostToDevice));
     // the Winograd F(2, 3) form of a 3x3 layer (conv_w1d): a measured experiment, slower than conv_t32 on every layer
     // (conv_w1d.hip), so only offered to the tuner with RMR_WINOGRAD=1
-    const bool wino = std::getenv("RMR_WINOGRAD") && std::atoi(std::getenv("RMR_WINOGRAD")) != 0;   // read per detector
+    const bool wino = conv_w1d_num_tiles() > 0 && std::getenv("RMR_WINOGRAD") && std::atoi(std::getenv("RMR_WINOGRAD")) != 0;   // read per detector; EXPERIMENTS=1 builds only
     if (wino && cw.k == 3) {
         std::vector<__half> pw;
         pack_conv_weights_w1d(packed.data(), cw.cout_pad, cw.cin, cw.Kp, pw);
@@ -637,7 +637,8 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
             }
         }
         for (const auto& kv : named_) only = only && kv.second.v.off != p.out.off;
-        p.q_only = only && readers == 1;
+        // a producer with a shortcut keeps its f16 output: the e4m3-only epilogue has no residual form (conv_t32f8 rejects it)
+        p.q_only = only && readers == 1 && !(p.res.c || p.res.cs);
     }
     if (arena_reuse_) compact_arenas();
     // Images per launch: every activation view (pixels x its buffer's channel pitch, plus the span of its
@@ -1101,8 +1102,17 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
                               op.in.h, op.in.w, op.in.c);
             break;
         case OP_HEAD: {
-            // consecutive scales leave in one launch: the first of a run decodes the run, the others have nothing left to do
-            if (op_index > 0 && ops_[op_index - 1].kind == OP_HEAD) break;   // (the planner emits the three scales' decodes together)
+            // consecutive scales leave in one launch.  ONE rule decides both who launches and what the launch covers: walk
+            // the stretch of consecutive OP_HEADs from its start and cut it into runs of up to three scales with the
+            // leader's class pitch; the leader of a run decodes the run, its other members have nothing left to do.
+            int b = op_index;
+            while (b > 0 && ops_[b - 1].kind == OP_HEAD) --b;
+            int lead = b, len = 0;
+            for (int i = b; i <= op_index; ++i) {
+                if (len == 3 || ops_[i].cls.cs != ops_[lead].cls.cs) lead = i, len = 0;
+                ++len;
+            }
+            if (lead != op_index) break;
             const float *box[3], *cls[3];
             int H[3], W[3], st[3], off[3], k = 0;
             for (int i = op_index; i < (int)ops_.size() && k < 3 && ops_[i].kind == OP_HEAD && ops_[i].cls.cs == op.cls.cs; ++i, ++k) {

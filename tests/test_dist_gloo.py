@@ -209,3 +209,67 @@ def test_file_transport_second_communicator_never_reads_stale_records(tmp_path):
     assert os.path.isdir(path) and not any(n.startswith("e1.") for n in os.listdir(path))
     close_all(first)
     assert not os.path.exists(path)
+
+
+def test_file_transport_epoch_is_collective_after_a_clean_close(tmp_path):
+    """ADVICE r03 (api_comm.cpp): rank 1 leaves a cleanly closed communicator before rank 0 has swept the directory and
+    at once joins the next one on the same path.  With per-rank epochs rank 1 (its old marker still there) and rank 0 (after
+    its sweep) chose different epochs and the gather timed out; the epoch is now handed out by rank 0 in the join
+    handshake, so both sessions and a third one after them exchange the right records."""
+    import threading
+    import time
+    sys.path.insert(0, ROOT)
+    from rm_radar_amd import dist as rd
+    path = str(tmp_path / "shared_dir")     # a caller-supplied directory: survives its communicators
+    os.makedirs(path)
+    uid = path.encode()
+    res = {}
+
+    def rank_main(rank):
+        for session in range(3):
+            comm = rd.Comm("file", rank, 2, uid)
+            mine = np.full((2, rd.RECORD_WORDS), session * 100 + rank, np.int32)
+            got = comm.all_gather_records(mine)
+            res[(session, rank)] = [int(got[src].flat[0]) for src in range(2)]
+            if rank == 0:
+                time.sleep(0.05)           # rank 1 is through its close and into the next create before rank 0 sweeps
+            comm.close()
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(90)
+    assert not any(t.is_alive() for t in th)
+    for session in range(3):
+        for rank in range(2):
+            assert res[(session, rank)] == [session * 100, session * 100 + 1], (session, rank, res)
+    assert not any(n.startswith(("hello.", "welcome.")) for n in os.listdir(path))
+
+
+def test_file_transport_restarted_rank_gets_the_current_epoch(tmp_path):
+    """A rank that crashed before the exchange leaves a hello file with a dead token; its restart publishes a new token
+    and rank 0 answers THAT one (a welcome for the dead token is ignored)."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from rm_radar_amd import dist as rd
+    path = str(tmp_path / "d")
+    os.makedirs(path)
+    open(os.path.join(path, "hello.1"), "w").write("12345")            # the crashed process's hello
+    open(os.path.join(path, "welcome.1"), "w").write("999 7")          # a stale answer to an even older one
+    open(os.path.join(path, "e4.3.1"), "wb").write(b"x" * 96)          # a record file an earlier epoch left behind
+    out = [None, None]
+
+    def run(rank):
+        c = rd.Comm("file", rank, 2, path.encode())
+        out[rank] = c.all_gather_records(np.full((2, rd.RECORD_WORDS), 40 + rank, np.int32))
+        c.close()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    th[0].start()
+    import time
+    time.sleep(0.2)                                                     # rank 0 has already answered the dead token
+    th[1].start()
+    for t in th:
+        t.join(60)
+    for rank in range(2):
+        assert [int(out[rank][s].flat[0]) for s in range(2)] == [40, 41]
+    assert os.path.exists(os.path.join(path, "e4.3.1"))                 # epoch 5 never touched epoch 4's files

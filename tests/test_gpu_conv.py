@@ -312,64 +312,6 @@ def test_conv_t32_every_tile(rmr):
                    False, tile=806)  # Cin = 48 is not a multiple of 32
 
 
-def wino_ref(x_nhwc, w, b, silu, res):
-    """F(2, 3) along x restated in torch with the kernel's roundings: V = B^T d (one f16 add of two f16 values), U = g G^T
-    rounded to f16 once, f32 accumulation, f32 output transform (tools/winograd_gate.py::winograd_conv_1d)"""
-    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
-    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float32)
-    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
-    x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2)
-    wt = torch.from_numpy(w)
-    B, C, H, W = x.shape
-    d = F.pad(x, (1, 1, 1, 1)).unfold(3, 4, 2)
-    V = torch.einsum("ij,bcyxj->bcyxi", BT, d).half().float()
-    U = torch.einsum("ij,kcrj->kcri", G, wt).half().float()
-    M = sum(torch.einsum("kci,bcyxi->bkyxi", U[:, :, r], V[:, :, r:r + H]) for r in range(3))
-    y = torch.einsum("ij,bkyxj->bkyxi", AT, M).reshape(B, wt.shape[0], H, W) + torch.from_numpy(b).view(1, -1, 1, 1)
-    if silu:
-        y = y * torch.sigmoid(y)
-    y = y.permute(0, 2, 3, 1).numpy()
-    return y + res if res is not None else y
-
-
-def run_wino_case(rmr, n, h, w, cin, cout, silu, res, tile, seed):
-    rng = np.random.default_rng(seed)
-    x = r16(rng.normal(0, 1, (n, h, w, cin)).astype(np.float32))
-    wt = r16((rng.normal(0, 1, (cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
-    b = rng.normal(0, 0.5, cout).astype(np.float32)
-    r = r16(rng.normal(0, 1, (n, h, w, cout)).astype(np.float32)) if res else None
-    got = rmr.conv2d(x, wt, b, 1, 1, silu, r, tile=tile)
-    scale = max(1.0, np.abs(got).max())
-    # (a) against its own arithmetic: only the f32 accumulation order differs -- the bar of every other kernel
-    err = np.abs(got - wino_ref(x, wt, b, silu, r)).max()
-    assert err <= 2e-3 * scale, f"vs the Winograd restatement: max err {err}"
-    # (b) against the direct convolution: what rounding V and U to f16 costs (2^-11 relative per operand, K = 12 Cin terms)
-    err = np.abs(got - ref_conv(x, wt, b, 1, 1, silu, r)).max()
-    assert err <= 1.2e-2 * scale, f"vs the direct convolution: max err {err}"
-
-
-def test_conv_w1d_every_tile(rmr):
-    # Winograd F(2, 3) along x on the conv_t32 skeleton (conv_w1d.hip, ids 980..): GEMM rows are 2-pixel tiles, four
-    # accumulator sets per wave tile, 12 (filter row, xi) slices per 32-channel chunk, the input transform in LDS with the
-    # left / right padding as lane masks, two strided epilogue passes
-    tiles = [(512, 96), (256, 192), (512, 64)]
-    for t, (bm, bn) in enumerate(tiles):
-        run_wino_case(rmr, 3, 20, 20, 64, bn, True, True, 980 + t, seed=t)              # 3 images, ~3 tiles, 2 chunks
-        run_wino_case(rmr, 1, 19, 22, 32, bn * 2, True, False, 980 + t, seed=40 + t)    # odd H, ragged M, 1 chunk, 2 channel tiles
-        run_wino_case(rmr, 2, 7, 6, 32, bn, False, False, 980 + t, seed=50 + t)         # 3 tiles per row; tile far larger than the images
-    run_wino_case(rmr, 2, 40, 40, 192, 192, True, True, 980, seed=70)    # 6 chunks, 72 taps
-    run_wino_case(rmr, 2, 40, 40, 192, 192, True, False, 981, seed=71)
-    run_wino_case(rmr, 1, 80, 80, 96, 96, True, True, 980, seed=72)      # W = 80: 43 raw blocks, 152 KiB of LDS
-    run_wino_case(rmr, 1, 80, 80, 192, 192, True, False, 981, seed=73)
-    run_wino_case(rmr, 2, 20, 20, 288, 288, True, True, 980, seed=74)    # 9 chunks, 3 channel tiles
-    run_wino_case(rmr, 1, 80, 80, 192, 64, True, False, 982, seed=75)    # Detect box branch shape
-    # more tiles than workgroups: every workgroup walks several tiles (the streams cross tile boundaries)
-    run_wino_case(rmr, 330, 20, 20, 32, 192, True, True, 980, seed=76)   # 258 x 2 tiles on 256 workgroups
-    run_wino_case(rmr, 330, 20, 20, 64, 192, True, False, 981, seed=77)  # 516 tiles of 256 x 192
-    with pytest.raises(rmr.InvalidArgument):
-        rmr.conv2d(np.zeros((1, 5, 5, 32), np.float32), np.zeros((96, 32, 3, 3), np.float32), None, 1, 1, False, tile=980)  # odd width
-
-
 def test_conv_g32_every_tile(rmr):
     # the gathered form of conv_t32 (conv_g32.hip, ids 950..): 1x1 layers and 3x3 layers of any stride, one
     # (tap, 32-channel chunk) stage = the tile's pixel rows at that tap + the weight slice, padding as
