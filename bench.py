@@ -92,7 +92,7 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=0, help="frame height, e.g. --size 1920 --height 1080 for configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="cpu_baseline: at most this many timed frames per worker")
+    ap.add_argument("--cpu-frames", type=int, default=1, help="cpu_baseline: timed frames per worker")
     ap.add_argument("--cpu-workers", type=int, default=0, help="cpu_baseline: frames in flight (0 = cores / 8)")
     ap.add_argument("--launch-order", default="", help="write the enqueue order of the profiled launches (layer, FLOPs, bytes) to this "
                     "file (RMR_PROFILE_ORDER): what tools/pmc_traffic.py maps the dispatches of a rocprofv3 --pmc pass with")
@@ -219,8 +219,8 @@ def cpu_baseline(args, packs, images, clouds, rects):
     """The same frames on the host CPU: C oracle (pre / decode+NMS / locate) + PyTorch-CPU fp32 YOLOv8m (oneDNN) standing in
     for ONNX-Runtime-CPU + PCL, which this image lacks.  SURVEY 8d: frames in parallel -- W workers (threads: torch's CPU
     ops and the ctypes oracle both release the GIL), each with its own Locator stream and its own share of the frames,
-    torch intra-op threads = cores / W per worker; cores = what this process may run on (sched_getaffinity).  One
-    untimed frame per worker warms the pools up and sizes the timed sample to about 12 s."""
+    torch intra-op threads = cores / W per worker; cores = what this process may run on (sched_getaffinity).  W = cores / 8
+    by default, one frame per worker: about 30 s on the GPU box's 256 cores."""
     from concurrent.futures import ThreadPoolExecutor
 
     import torch
@@ -260,16 +260,16 @@ def cpu_baseline(args, packs, images, clouds, rects):
             list(ex.map(work, range(workers)))
         return time.perf_counter() - t0
 
-    warm = run(1, 0)
-    per_worker = max(1, min(args.cpu_frames, int(12.0 / max(warm, 1e-3))))
-    dt = run(per_worker, workers)
+    # no warm-up frame: a frame is tens of seconds of CPU work at these thread counts, the pools' spin-up is not
+    per_worker = max(1, args.cpu_frames)
+    dt = run(per_worker, 0)
     torch.set_num_threads(prev_threads)
     n = workers * per_worker
     return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "workers": workers, "threads_per_worker": threads,
             "sample": f"{n} frame(s) of the same workload ({workers} workers x {per_worker} frame(s), {threads} torch intra-op "
                       f"threads each; per frame 1 car + {args.crops} armor YOLOv8m forwards in PyTorch-CPU fp32, C oracle "
-                      f"pre/post/locate on the worker's own Locator stream), {dt:.1f} s timed after one warm-up frame per worker ({warm:.1f} s)"}
+                      f"pre/post/locate on the worker's own Locator stream), {dt:.1f} s"}
 
 
 PLAN_DIR = os.path.join(ROOT, "profiles", "plans")

@@ -30,15 +30,30 @@ for dtype in (sys.argv[1:] or ["f16", "fp8"]):
     packs = (os.path.join(d, "car.rmrw"), os.path.join(d, "armor.rmrw"))
     W.make_synthetic_pack(packs[0], "m", 1, seed=1, cls_bias=-6.0)
     W.make_synthetic_pack(packs[1], "m", 12, seed=2, cls_bias=-6.0)
+    merged = [{}, {}]   # (op, n) -> choice per pack; a detector re-writes its cache with the entries of ITS batch sizes only
+    headers = [None, None]
     for batch in ((64, 1) if dtype == "f16" else (256, 64, 1)):
         args = bench.parse(["--batch", str(batch), "--dtype", dtype])
         images, clouds, rects = bench.make_inputs(args, 0)
+        for pk in packs:
+            if os.path.exists(pk + ".tune"):
+                os.remove(pk + ".tune")
         rdet = rmr.RobotDetector(packs[0], packs[1], (640, 640), 12, max_cars=4, opt_cars=4, max_frames=batch, precision=dtype)
         loc = rmr.Locator(640, 640, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32), max_frames=batch)
         for _ in range(2):
             rmr.run_batch(rdet, loc, list(images), list(clouds), np.ascontiguousarray(rects, np.int32))
         rdet.close()
         loc.close()
-    for pk, f in zip(packs, bench.plan_files(args, out)):
-        shutil.copyfile(pk + ".tune", f)
-        print(f, sum(1 for _ in open(f)) - 1, "entries")
+        for i, pk in enumerate(packs):
+            lines = open(pk + ".tune").read().splitlines()
+            assert headers[i] in (None, lines[0]), "the plan signature changed between batch sizes"
+            headers[i] = lines[0]
+            for ln in lines[1:]:
+                op, n, choice = (int(v) for v in ln.split())
+                merged[i][(op, n)] = choice
+    for i, f in enumerate(bench.plan_files(args, out)):
+        with open(f, "w") as fh:
+            fh.write(headers[i] + "\n")
+            for (op, n), choice in sorted(merged[i].items()):
+                fh.write(f"{op} {n} {choice}\n")
+        print(f, len(merged[i]), "entries, batch sizes", sorted({n for _, n in merged[i]}))
