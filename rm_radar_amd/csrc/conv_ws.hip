@@ -27,6 +27,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 #include "conv_igemm.h"
 
@@ -346,10 +347,359 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
     wait_vmw<0>();
 }
 
-// variant = strip height x wave layout (NJ = 1 for ids 0..5, NJ = 3 for ids 6..11)
+// =====================================================================================================================
+// conv_wsp_kernel (round 4): the same weights-stationary walk, software-pipelined per 16-pixel tile.
+//
+// What the kernel above loses (measured, 256 images, w0: 456 us per launch = 13 000 cycles per two-row step against 3 360
+// cycles of MFMA work per SIMD; without the SiLU 365 us; with a shortcut 541 us): its wave runs K-outer -- 14 K steps over
+// five pixel tiles -- so the 60 epilogue values per lane (two transcendentals each), the 24 vector-memory instructions of a
+// step (60-180 issue cycles each) and the LDS traffic of the stage all sit in the SAME in-order instruction stream as the
+// MFMAs: with one wave per SIMD nothing runs beside anything.  Here
+//   * a wave runs TILE-outer: the 42 MFMAs of tile g (14 K steps x 3 channel tiles) carry, as fillers between them, the bias + SiLU of tile g - 1 (one value per K step, results into the wave's
+//     own 3 KiB stage) and the drain of tile g - 2 (stage -> 16-byte chunks, + the shortcut pixels fetched as
+//     16-byte chunks into registers one tile earlier, -> two bounds-checked stores): every stage of a tile's life rides
+//     under another tile's MFMAs, and the f32 sum SiLU + shortcut is still rounded to f16 once (f32 stage);
+//   * only 12 accumulators are live at a time, so a wave needs ~250 registers with the whole filter resident (168)
+//     and TWO waves fit a SIMD (NSPLIT = 2: waves w and w + 4 share the half row of SIMD w, three tiles + two tiles):
+//     one wave's vector-memory issue and transcendentals run beside the other's MFMAs;
+//   * same ring of rows, same DMAs, same barrier per step; the same f32 operation order per output value as the kernel
+//     above (K steps in order on one accumulator, then the bias), so the two are bit-identical.
+// vmcnt discipline (loads and stores retire in order): the shortcut loads of a tile are issued after that tile loop's two
+// stores and before its row DMAs, and are waited for one tile loop later with vmcnt(row DMAs issued since).
+constexpr int WP_SLOTS = 8;
+constexpr int WP_STAGE = 3072;   // per wave: one tile of 16 pixels x 48 channels as f32 (shortcut) or f16
+constexpr int wp_lds(int nw) { return WP_SLOTS * WS_ROW + nw * WP_STAGE + 1024 + 256; }  // + idle-DMA KiB + bias
+
+__device__ __forceinline__ u32x4 ld16_asm(u32x4 rsrc, unsigned voff) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+    return v;
+}
+
+template <bool ACT, bool RES, bool OUT32, int NSPLIT>
+__global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a, const int strip_rows) {
+    constexpr int NW = 4 * NSPLIT;
+    constexpr int NI = (2 * WS_DMA_ROW + NW - 1) / NW;   // row-pair DMA instructions per wave and step: 8 / 4
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave & 3;          // the half row of SIMD `grp` (waves w and w + 4 share a SIMD)
+    const int sub = wave >> 2;         // NSPLIT = 2: 0 = tiles 0..2 of the half row, 1 = tiles 3..4
+    const int r = grp >> 1, xh = grp & 1;
+    const int t0 = NSPLIT == 2 && sub ? 3 : 0;
+    const int frow = lane & 15, kg = lane >> 4;
+    const bool hi = kg >= 2;
+
+    const int strips = a.H / strip_rows;
+    const int img = blockIdx.x / strips;
+    const int y_base = (blockIdx.x % strips) * strip_rows;
+    const int steps = strip_rows / 2;
+
+    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
+                           sgpr(a.in_bytes), sgpr(0x00020000u)};
+    unsigned char* const stage_p = smem + WP_SLOTS * WS_ROW + wave * WP_STAGE;
+    const unsigned scratch = sgpr(lds0 + WP_SLOTS * WS_ROW + NW * WP_STAGE);
+    float* const bias_p = (float*)(smem + WP_SLOTS * WS_ROW + NW * WP_STAGE + 1024);
+
+    for (int i = tid; i < WP_SLOTS * 2 * (WS_PIX / 16); i += 64 * NW) {
+        const int slot = i / (2 * (WS_PIX / 16));
+        const int rem = i % (2 * (WS_PIX / 16));
+        const int side = rem / (WS_PIX / 16), c16 = rem % (WS_PIX / 16);
+        *(u32x4*)(smem + slot * WS_ROW + side * (WS_W + 1) * WS_PIX + c16 * 16) = u32x4{0, 0, 0, 0};
+    }
+    if (tid < WS_C) bias_p[tid] = a.bias[tid];
+    __syncthreads();
+
+    half8 wreg[WS_KSTEPS][3];
+#pragma unroll
+    for (int ks = 0; ks < WS_KSTEPS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            wreg[ks][j] = *(const half8*)((const _Float16*)a.wt + (size_t)(j * 16 + frow) * a.Kp + ks * 32 + kg * 8);
+#pragma unroll
+    for (int ks = 0; ks < WS_KSTEPS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(wreg[ks][j]));
+
+    // ---- row-pair DMAs: as in the kernel above, NW waves share the 30 instructions of a pair ----
+    unsigned goff[NI], q_ok[NI], q_row[NI], q_dst[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int q = wave + NW * j;
+        const int g = (q % WS_DMA_ROW) * 64 + lane;
+        goff[j] = (unsigned)(((g / 6) * a.in_cs + a.in_co + (g % 6) * 8) * 2);
+        q_ok[j] = q < 2 * WS_DMA_ROW ? 0xffffffffu : 0u;
+        q_row[j] = q >= WS_DMA_ROW ? 0xffffffffu : 0u;
+        q_dst[j] = (unsigned)(WS_PIX + (q % WS_DMA_ROW) * 1024);
+    }
+    const int img_row0 = img * a.H;
+    struct Pair {
+        unsigned live0, live1, rowoff0, slot0, slot1;
+    };
+    const unsigned row_bytes = (unsigned)(WS_W * a.in_cs * 2);
+    auto pair_of = [&](int ry0) {
+        const int gy0 = y_base - 1 + ry0;
+        Pair p;
+        p.live0 = (gy0 >= 0 && gy0 < a.H && ry0 <= strip_rows + 1) ? 0xffffffffu : 0u;
+        p.live1 = (gy0 + 1 >= 0 && gy0 + 1 < a.H && ry0 + 1 <= strip_rows + 1) ? 0xffffffffu : 0u;
+        p.rowoff0 = (unsigned)(img_row0 + gy0) * row_bytes;
+        p.slot0 = lds0 + (unsigned)(ry0 % WP_SLOTS) * WS_ROW;
+        p.slot1 = lds0 + (unsigned)((ry0 + 1) % WP_SLOTS) * WS_ROW;
+        return p;
+    };
+    auto issue_slot = [&](const Pair& p, int j) {
+        const unsigned live = q_ok[j] & ((q_row[j] & p.live1) | (~q_row[j] & p.live0));
+        const unsigned rowoff = p.rowoff0 + (q_row[j] & row_bytes);
+        const unsigned off = (goff[j] + rowoff) | ~live;
+        const unsigned slot = (q_row[j] & p.slot1) | (~q_row[j] & p.slot0);
+        const unsigned dst = (q_ok[j] & (slot + q_dst[j])) | (~q_ok[j] & scratch);
+        dma16w(in_rsrc, sgpr(dst), off);
+    };
+    auto issue_pair = [&](int ry0) {
+        const Pair p = pair_of(ry0);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) issue_slot(p, j);
+    };
+    issue_pair(0);
+    issue_pair(2);
+    issue_pair(4);
+
+    // ---- per-lane constants ----
+    // fragment reads: within one filter row the im2col index k' = kw * 48 + ci is LINEAR in the ring row's bytes (taps are
+    // neighbouring 96-byte pixels), so a lane's address is base(filter row) + 2 k' and lane group kg adds 16 kg; only K
+    // step 4 (k = 128..159: lanes 0-31 in filter row 0, lanes 32-63 in row 1) and step 13 (k >= 432: zero weights, lanes
+    // 32-63 re-read what lanes 0-31 read) select per lane.
+    const unsigned lane_off = (unsigned)(frow * WS_PIX + kg * 16 + (xh * 80 + t0 * 16) * WS_PIX);
+    const int px = lane & 15, cq = (lane >> 4) * 4;
+    // MFMA layout -> stage (pixel-major; f32 when a shortcut is added at the drain, else f16)
+    unsigned char* const sw = stage_p + (RES ? px * 192 + cq * 4 : px * 96 + cq * 2);
+    // drain layout: chunk c = 16 bytes of output = 8 channels; six chunks per pixel; lane l drains chunks l and 64 + l (l < 32)
+    const int c0 = lane, c1 = 64 + lane;
+    const unsigned char* const sr0 = stage_p + (RES ? (c0 / 6) * 192 + (c0 % 6) * 32 : c0 * 16);
+    const unsigned char* const sr1 = stage_p + (RES ? ((c1 % 96) / 6) * 192 + ((c1 % 96) % 6) * 32 : (c1 % 96) * 16);
+    const unsigned dead1 = c1 < 96 ? 0u : 0xffffffffu;
+    const unsigned oo0 = (unsigned)(((c0 / 6) * a.out_cs + a.out_co + (c0 % 6) * 8) * 2);
+    const unsigned oo1 = (unsigned)((((c1 % 96) / 6) * a.out_cs + a.out_co + ((c1 % 96) % 6) * 8) * 2) | dead1;
+    const unsigned ro0 = (unsigned)(((c0 / 6) * a.res_cs + a.res_co + (c0 % 6) * 8) * 2);
+    const unsigned ro1 = (unsigned)((((c1 % 96) / 6) * a.res_cs + a.res_co + ((c1 % 96) % 6) * 8) * 2) | dead1;
+    const u32x4 res_rsrc = {sgpr((unsigned)(size_t)a.res), sgpr((unsigned)((size_t)a.res >> 32) & 0xffffu),
+                            sgpr(RES ? 0xfffffff0u : 0u), sgpr(0x00020000u)};
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, OUT32 ? 0u : 0xfffffff0u, 0x00020000);
+
+    // ---- the tile pipeline's carried state ----
+    floatx4 acc[3], pacc[3];            // tile g, tile g - 1
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pacc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    unsigned ob1 = 0xffffffffu, ob2 = 0xffffffffu;   // output byte offset of the first pixel of tiles g - 1, g - 2 (all ones: none)
+    unsigned rb1 = 0xffffffffu;                      // the same in the shortcut tensor, tile g - 1
+    long pm1 = 0;                                    // OUT32: pixel index of tile g - 1 (-1: none)
+    bool pv1 = false;
+    u32x4 rres0 = {0, 0, 0, 0}, rres1 = {0, 0, 0, 0};   // shortcut chunks of tile g - 2
+    half8 xf[3];
+    unsigned A0 = 0, A1 = 0, A2 = 0;
+
+    // fragment read of (tile ii of this wave, K step ks) into xf[slot]
+    const auto read_frag = [&](int ii, int ks, int slot) {
+        const int kh = ks <= 4 ? 0 : ks <= 8 ? 1 : 2;
+        const unsigned base = ks == 4 ? (hi ? A1 - 32u : A0 + 256u) : ks == 13 ? A2 + 256u - (hi ? 32u : 0u) : kh == 0 ? A0 : kh == 1 ? A1 : A2;
+        const int imm = (ks == 4 || ks == 13 ? 0 : 2 * (32 * ks - 144 * kh)) + ii * 16 * WS_PIX;
+        xf[slot] = *(const __attribute__((address_space(3))) half8*)(size_t)(base + (unsigned)imm);
+    };
+    // B phase: value v (0..11) of tile g - 1
+    float bv[4];
+    floatx4 bj;
+    const auto b_value = [&](int v) {
+        const int j = v >> 2, e = v & 3;
+        if (e == 0) bj = *(const floatx4*)(bias_p + j * 16 + cq);
+        float x = pacc[j][e] + bj[e];    // the K steps in order on a zero accumulator, then the bias: the order of the kernel above
+        if (ACT) x = silu_w(x);
+        bv[e] = x;
+        if (e == 3) {
+            if (OUT32) {
+                if (pv1) {
+                    float* const o = a.out32 + (pm1 + px) * a.out_cs + a.out_co + j * 16 + cq;
+                    if (RES) {
+                        const __half* const rp = a.res + (pm1 + px) * a.res_cs + a.res_co + j * 16 + cq;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) bv[t] += __half2float(rp[t]);
+                    }
+                    *(float4*)o = make_float4(bv[0], bv[1], bv[2], bv[3]);
+                }
+            } else if (RES) {
+                *(float4*)(sw + j * 64) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+            } else {
+                union {
+                    uint2 u;
+                    _Float16 h[4];
+                } o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o.h[t] = (_Float16)bv[t];
+                *(uint2*)(sw + j * 32) = o.u;
+            }
+        }
+    };
+    // C phase: drain of tile g - 2, chunk 0 / 1: stage (+ shortcut) -> one 16-byte store
+    u32x4 cda, cdb;
+    const auto c_read = [&](int c) {
+        if (OUT32) return;
+        const unsigned char* const p = c ? sr1 : sr0;
+        cda = *(const u32x4*)p;
+        if (RES) cdb = *(const u32x4*)(p + 16);
+    };
+    const auto c_store = [&](int c) {
+        if (OUT32) return;
+        u32x4 o;
+        if (RES) {
+            const u32x4 fa = cda, fb = cdb, rr = c ? rres1 : rres0;
+            union {
+                u32x4 v;
+                _Float16 h[8];
+            } rh, oh;
+            rh.v = rr;
+            const float f[8] = {__uint_as_float(fa[0]), __uint_as_float(fa[1]), __uint_as_float(fa[2]), __uint_as_float(fa[3]),
+                                __uint_as_float(fb[0]), __uint_as_float(fb[1]), __uint_as_float(fb[2]), __uint_as_float(fb[3])};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) oh.h[t] = (_Float16)(f[t] + (float)rh.h[t]);
+            o = oh.v;
+        } else {
+            o = cda;
+        }
+        const unsigned off = ob2 == 0xffffffffu ? 0xffffffffu : ob2 + (c ? oo1 : oo0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
+    };
+
+    // One tile loop.  ii: this wave's tile within the step (compile time); T: its tiles per step; LAST: the step's last tile
+    // (no prefetch across the barrier).  DPREV: row DMAs issued in the previous tile loop (after its shortcut loads).
+    const auto tile_loop = [&](auto II, auto TT, const Pair& pair, unsigned ob0, unsigned rb0, long pm0) {
+        constexpr int ii = decltype(II)::value, T = decltype(TT)::value;
+        constexpr int prev = (ii + T - 1) % T;
+        constexpr int DPREV = (NI - 4 * prev) < 0 ? 0 : (NI - 4 * prev) > 4 ? 4 : (NI - 4 * prev);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < WS_KSTEPS; ++ks) {
+            // fragment reads two K steps ahead (into the next tile of the step where there is one); the three fragment
+            // registers rotate over the step's K steps, not the tile's (14 is not a multiple of 3)
+            constexpr int G0 = ii * WS_KSTEPS;
+            if (ks + 2 < WS_KSTEPS)
+                read_frag(ii, ks + 2, (G0 + ks + 2) % 3);
+            else if (ii + 1 < T)
+                read_frag(ii + 1, ks + 2 - WS_KSTEPS, (G0 + ks + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][j], xf[(G0 + ks) % 3], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) {
+                if (RES && !OUT32) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rres0), "+v"(rres1) : "n"(DPREV));
+                asm volatile("" ::: "memory");   // the stage was written through other pointer types in the last tile loop
+                c_read(0);
+            }
+            if (ks == 1) {   // one chunk at a time: the staged f32 values of both would cost 16 registers
+                c_store(0);
+                c_read(1);
+            }
+            if (ks == 2) c_store(1);
+            if (ks == 3 && RES && !OUT32) {   // shortcut chunks of tile g - 1 (drained in the next tile loop)
+                rres0 = ld16_asm(res_rsrc, rb1 == 0xffffffffu ? 0xffffffffu : rb1 + ro0);
+                rres1 = ld16_asm(res_rsrc, rb1 == 0xffffffffu ? 0xffffffffu : rb1 + ro1);
+            }
+            if (ks >= 2) b_value(ks - 2);
+            if (ks >= 5 && (ks & 1) && ks <= 11) {
+                const int slot = ii * 4 + (ks - 5) / 2;
+                if (slot < NI) issue_slot(pair, slot);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // tile g becomes tile g - 1
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pacc[j] = acc[j];
+        ob2 = ob1;
+        ob1 = ob0;
+        rb1 = rb0;
+        pm1 = pm0;
+        pv1 = true;
+    };
+
+    const auto run = [&](auto TT) {
+        constexpr int T = decltype(TT)::value;
+        constexpr int OPS = T * ((OUT32 ? 0 : 2) + (RES && !OUT32 ? 2 : 0)) + NI;          // vector-memory instructions per step
+        constexpr int LASTD = (NI - 1) / 4;                                                  // tile loop of a step's last row DMA
+        constexpr int AFTER = (T - 1 - LASTD) * ((OUT32 ? 0 : 2) + (RES && !OUT32 ? 2 : 0)); // ... and what the step issues behind it
+        static_assert(OPS + AFTER <= 63, "vmcnt is 6 bits");
+        for (int s = 0; s < steps; ++s) {
+            // rows of this step: issued two steps ago (or by the prologue)
+            if (s == 0)
+                wait_vmw<NI>();
+            else if (s == 1)
+                wait_vmw<OPS>();
+            else
+                wait_vmw<OPS + AFTER>();
+            __builtin_amdgcn_s_barrier();
+            const Pair pair = pair_of(2 * s + 6);
+            const int y = y_base + 2 * s + r;
+            const long m_row = ((long)img_row0 + y) * WS_W + xh * 80 + t0 * 16;
+            const unsigned vb0 = lds0 + ((2 * s + r + 0) % WP_SLOTS) * WS_ROW + lane_off;
+            const unsigned vb1 = lds0 + ((2 * s + r + 1) % WP_SLOTS) * WS_ROW + lane_off;
+            const unsigned vb2 = lds0 + ((2 * s + r + 2) % WP_SLOTS) * WS_ROW + lane_off;
+            A0 = vb0, A1 = vb1, A2 = vb2;
+            read_frag(0, 0, 0);
+            read_frag(0, 1, 1);
+            const unsigned ob = OUT32 ? 0u : (unsigned)(m_row * a.out_cs * 2);
+            const unsigned rb = RES && !OUT32 ? (unsigned)(m_row * a.res_cs * 2) : 0u;
+            const unsigned ostep = OUT32 ? 0u : (unsigned)(16 * a.out_cs * 2), rstep = RES && !OUT32 ? (unsigned)(16 * a.res_cs * 2) : 0u;
+            tile_loop(std::integral_constant<int, 0>{}, TT, pair, ob, rb, m_row);
+            if constexpr (T > 1) tile_loop(std::integral_constant<int, 1>{}, TT, pair, ob + ostep, rb + rstep, m_row + 16);
+            if constexpr (T > 2) tile_loop(std::integral_constant<int, 2>{}, TT, pair, ob + 2 * ostep, rb + 2 * rstep, m_row + 32);
+            if constexpr (T > 3) tile_loop(std::integral_constant<int, 3>{}, TT, pair, ob + 3 * ostep, rb + 3 * rstep, m_row + 48);
+            if constexpr (T > 4) tile_loop(std::integral_constant<int, 4>{}, TT, pair, ob + 4 * ostep, rb + 4 * rstep, m_row + 64);
+        }
+        // ---- the strip's tail: B phase of the last tile, C phase of the last two (nothing left to hide them under) ----
+        if (RES && !OUT32) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres0), "+v"(rres1));
+        asm volatile("" ::: "memory");
+        c_read(0);
+        c_store(0);
+        c_read(1);
+        c_store(1);
+        asm volatile("" ::: "memory");
+        if (RES && !OUT32) {
+            rres0 = ld16_asm(res_rsrc, rb1 + ro0);
+            rres1 = ld16_asm(res_rsrc, rb1 + ro1);
+        }
+#pragma unroll
+        for (int v = 0; v < 12; ++v) b_value(v);
+        ob2 = ob1;
+        if (RES && !OUT32) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres0), "+v"(rres1));
+        asm volatile("" ::: "memory");
+        c_read(0);
+        c_store(0);
+        c_read(1);
+        c_store(1);
+        wait_vmw<0>();
+    };
+    if (NSPLIT == 1)
+        run(std::integral_constant<int, 5>{});
+    else if (sub == 0)
+        run(std::integral_constant<int, 3>{});
+    else
+        run(std::integral_constant<int, 2>{});
+}
+
+// variant = strip height x wave layout (NJ = 1 for ids 0..5, NJ = 3 for ids 6..11); 12..: the pipelined kernel
 const int kWsStripRows[] = {40, 20, 10, 8, 4, 2};
 constexpr int kNumStrips = sizeof(kWsStripRows) / sizeof(kWsStripRows[0]);
-constexpr int kNumWs = 2 * kNumStrips;
+constexpr int kNumWsOld = 2 * kNumStrips;
+struct WspVariant {
+    int strip_rows, nsplit;
+};
+const WspVariant kWsp[] = {{160, 2}, {80, 2}, {40, 2}, {20, 2}, {10, 2}, {160, 1}, {40, 1}, {10, 1}};   // ids 12..19
+constexpr int kNumWsp = sizeof(kWsp) / sizeof(kWsp[0]);
+constexpr int kNumWs = kNumWsOld + kNumWsp;
 
 }  // namespace
 
@@ -360,7 +710,8 @@ bool conv_ws_supported(const ConvArgs& a, int variant) {
     if (a.Cin != WS_C || a.Cout_pad != WS_C || a.W != WS_W || a.Wo != a.W || a.Ho != a.H) return false;
     if (a.Kp < WS_KSTEPS * 32 || (!a.out32 && !a.out)) return false;
     if (variant < 0) return a.H % 2 == 0;
-    return variant < kNumWs && a.H % kWsStripRows[variant % kNumStrips] == 0;
+    if (variant >= kNumWsOld) return variant < kNumWs && a.H % kWsp[variant - kNumWsOld].strip_rows == 0;
+    return a.H % kWsStripRows[variant % kNumStrips] == 0;
 }
 
 void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant) {
@@ -378,15 +729,28 @@ void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
      conv_ws_kernel<true, true, false, NJ>,   conv_ws_kernel<true, true, true, NJ>}
     static const Kern kernels[2][8] = {WS_KERNELS(1), WS_KERNELS(3)};
 #undef WS_KERNELS
+#define WSP_KERNELS(NS)                                                                                    \
+    {conv_wsp_kernel<false, false, false, NS>, conv_wsp_kernel<false, false, true, NS>,                    \
+     conv_wsp_kernel<false, true, false, NS>,  conv_wsp_kernel<false, true, true, NS>,                     \
+     conv_wsp_kernel<true, false, false, NS>,  conv_wsp_kernel<true, false, true, NS>,                     \
+     conv_wsp_kernel<true, true, false, NS>,   conv_wsp_kernel<true, true, true, NS>}
+    static const Kern pkernels[2][8] = {WSP_KERNELS(1), WSP_KERNELS(2)};
+#undef WSP_KERNELS
     static std::once_flag once;
     std::call_once(once, [] {
         for (const auto& row : kernels)
             for (Kern k : row)
                 (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (const auto& row : pkernels)
+            for (Kern k : row)
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    const int nj = variant < kNumStrips ? 1 : 3;
-    const Kern kernel = kernels[nj == 1 ? 0 : 1][(a.act ? 4 : 0) + (a.res ? 2 : 0) + (a.out32 ? 1 : 0)];
-    const int sr = kWsStripRows[variant % kNumStrips];
+    const bool piped = variant >= kNumWsOld;
+    const int nj = piped ? 1 : variant < kNumStrips ? 1 : 3;
+    const int nsplit = piped ? kWsp[variant - kNumWsOld].nsplit : 1;
+    const int kidx = (a.act ? 4 : 0) + (a.res ? 2 : 0) + (a.out32 ? 1 : 0);
+    const Kern kernel = piped ? pkernels[nsplit - 1][kidx] : kernels[nj == 1 ? 0 : 1][kidx];
+    const int sr = piped ? kWsp[variant - kNumWsOld].strip_rows : kWsStripRows[variant % kNumStrips];
     const int grid = a.N * (a.H / sr);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
@@ -401,7 +765,10 @@ void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
         pname = names.emplace(buf, buf).first->second.c_str();
     }
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
-    kernel<<<grid, 256 * nj, ws_lds(nj), stream>>>(a, sr);
+    if (piped)
+        kernel<<<grid, 256 * nsplit, wp_lds(4 * nsplit), stream>>>(a, sr);
+    else
+        kernel<<<grid, 256 * nj, ws_lds(nj), stream>>>(a, sr);
     RMR_HIP(hipGetLastError());
 }
 
