@@ -170,7 +170,16 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         a.pad = pad;
         a.wt = dw.p;
         a.bias = db.p;
-        a.out32 = dy.p;
+        // RMR_CONV2D_OUT16=1 (tests): the layer writes its f16 view, as inside the network -- the kernels' production
+        // epilogues (LDS stages, 16-byte stores, in-register shortcut adds) instead of their f32 parity view
+        const bool out16 = std::getenv("RMR_CONV2D_OUT16") && std::atoi(std::getenv("RMR_CONV2D_OUT16")) != 0;
+        DevBuf<__half> dy16;
+        if (out16) {
+            dy16.alloc(npx_out * cout_pad);
+            a.out = dy16.p;
+        } else {
+            a.out32 = dy.p;
+        }
         a.out_cs = cout_pad;
         if (residual) {
             a.res = dr.p;
@@ -321,8 +330,15 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             launch_conv(ctx, ctx.stream, a, tile);
         }
         std::vector<float> hy(npx_out * cout_pad);
-        RMR_HIP(hipMemcpyAsync(hy.data(), dy.p, hy.size() * sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
-        RMR_HIP(hipStreamSynchronize(ctx.stream));
+        if (out16) {
+            std::vector<__half> hy16(hy.size());
+            RMR_HIP(hipMemcpyAsync(hy16.data(), dy16.p, hy16.size() * sizeof(__half), hipMemcpyDeviceToHost, ctx.stream));
+            RMR_HIP(hipStreamSynchronize(ctx.stream));
+            for (size_t i = 0; i < hy.size(); ++i) hy[i] = __half2float(hy16[i]);
+        } else {
+            RMR_HIP(hipMemcpyAsync(hy.data(), dy.p, hy.size() * sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
+            RMR_HIP(hipStreamSynchronize(ctx.stream));
+        }
         if (want_timing) {
             long long t[8] = {0};
             RMR_HIP(hipMemcpy(t, dtiming.p, 64, hipMemcpyDeviceToHost));

@@ -376,7 +376,10 @@ __device__ __forceinline__ u32x4 ld16_asm(u32x4 rsrc, unsigned voff) {
     return v;
 }
 
-template <bool ACT, bool RES, bool OUT32, int NSPLIT>
+// ABL (development builds, -DRMR_WSP_ABLATE + RMR_WSP_ABLATE=<mask> in the environment): parts removed to price them --
+// 1 no MFMAs, 2 no stores, 4 row DMAs out of range (issued, nothing fetched), 8 no fragment reads, 16 no transcendentals,
+// 32 shortcut loads out of range, 64 no barrier
+template <bool ACT, bool RES, bool OUT32, int NSPLIT, int ABL = 0>
 __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a, const int strip_rows) {
     constexpr int NW = 4 * NSPLIT;
     constexpr int NI = (2 * WS_DMA_ROW + NW - 1) / NW;   // row-pair DMA instructions per wave and step: 8 / 4
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
     const int steps = strip_rows / 2;
 
     const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu),
-                           sgpr(a.in_bytes), sgpr(0x00020000u)};
+                           sgpr((ABL & 4) ? 0u : a.in_bytes), sgpr(0x00020000u)};
     unsigned char* const stage_p = smem + WP_SLOTS * WS_ROW + wave * WP_STAGE;
     const unsigned scratch = sgpr(lds0 + WP_SLOTS * WS_ROW + NW * WP_STAGE);
     float* const bias_p = (float*)(smem + WP_SLOTS * WS_ROW + NW * WP_STAGE + 1024);
@@ -479,24 +482,36 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
     // MFMA layout -> stage (pixel-major; f32 when a shortcut is added at the drain, else f16)
     unsigned char* const sw = stage_p + (RES ? px * 192 + cq * 4 : px * 96 + cq * 2);
     // drain layout: chunk c = 16 bytes of output = 8 channels; six chunks per pixel; lane l drains chunks l and 64 + l (l < 32)
-    const int c0 = lane, c1 = 64 + lane;
-    const unsigned char* const sr0 = stage_p + (RES ? (c0 / 6) * 192 + (c0 % 6) * 32 : c0 * 16);
-    const unsigned char* const sr1 = stage_p + (RES ? ((c1 % 96) / 6) * 192 + ((c1 % 96) % 6) * 32 : (c1 % 96) * 16);
-    const unsigned dead1 = c1 < 96 ? 0u : 0xffffffffu;
-    const unsigned oo0 = (unsigned)(((c0 / 6) * a.out_cs + a.out_co + (c0 % 6) * 8) * 2);
-    const unsigned oo1 = (unsigned)((((c1 % 96) / 6) * a.out_cs + a.out_co + ((c1 % 96) % 6) * 8) * 2) | dead1;
-    const unsigned ro0 = (unsigned)(((c0 / 6) * a.res_cs + a.res_co + (c0 % 6) * 8) * 2);
-    const unsigned ro1 = (unsigned)((((c1 % 96) / 6) * a.res_cs + a.res_co + ((c1 % 96) % 6) * 8) * 2) | dead1;
+    // (pixel, part) of the two chunks packed into ONE register: the byte offsets into the stage, the output and the
+    // shortcut tensor are two multiply-adds away when they are needed (registers are what limits two waves per SIMD)
+    const int c0 = lane, c1 = (64 + lane) % 96;
+    const unsigned pq = (unsigned)((c0 / 6) | ((c0 % 6) << 4) | ((c1 / 6) << 8) | ((c1 % 6) << 12) | (lane >= 32 ? 1 << 16 : 0));
+    // (read through an empty asm at every use: otherwise the optimiser hoists the derived offsets out of the step loop and
+    // they occupy the registers this packing is meant to free)
+    const auto pqv = [&]() {
+        unsigned q = pq;
+        asm volatile("" : "+v"(q));
+        return q;
+    };
+    const auto cp = [&](int c) { return (pqv() >> (c ? 8 : 0)) & 15u; };
+    const auto cqq = [&](int c) { return (pqv() >> (c ? 12 : 4)) & 15u; };
+    const auto dead = [&](int c) { return c ? 0u - ((pqv() >> 16) & 1u) : 0u; };   // all ones: lanes 32-63 have no second chunk
+    const auto stage_rd = [&](int c) { return stage_p + (RES ? cp(c) * 192u + cqq(c) * 32u : cp(c) * 96u + cqq(c) * 16u); };
+    const unsigned out_pitch2 = (unsigned)a.out_cs * 2u, out_co2 = (unsigned)a.out_co * 2u;
+    const unsigned res_pitch2 = (unsigned)a.res_cs * 2u, res_co2 = (unsigned)a.res_co * 2u;
+    const auto out_off = [&](int c) { return cp(c) * out_pitch2 + out_co2 + cqq(c) * 16u; };
+    const auto res_off = [&](int c) { return cp(c) * res_pitch2 + res_co2 + cqq(c) * 16u; };
     const u32x4 res_rsrc = {sgpr((unsigned)(size_t)a.res), sgpr((unsigned)((size_t)a.res >> 32) & 0xffffu),
-                            sgpr(RES ? 0xfffffff0u : 0u), sgpr(0x00020000u)};
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, OUT32 ? 0u : 0xfffffff0u, 0x00020000);
+                            sgpr(RES && !(ABL & 32) ? 0xfffffff0u : 0u), sgpr(0x00020000u)};
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, OUT32 || (ABL & 2) ? 0u : 0xfffffff0u, 0x00020000);
 
     // ---- the tile pipeline's carried state ----
     floatx4 acc[3], pacc[3];            // tile g, tile g - 1
 #pragma unroll
     for (int j = 0; j < 3; ++j) pacc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    unsigned ob1 = 0xffffffffu, ob2 = 0xffffffffu;   // output byte offset of the first pixel of tiles g - 1, g - 2 (all ones: none)
-    unsigned rb1 = 0xffffffffu;                      // the same in the shortcut tensor, tile g - 1
+    // output byte offset of the first pixel of tiles g - 1, g - 2, and the same in the shortcut tensor for tile g - 1; inv*:
+    // all ones while there is no such tile yet (the offset is OR-ed out of range: no branch inside the tile loop)
+    unsigned ob1 = 0, ob2 = 0, rb1 = 0, inv1 = 0xffffffffu, inv2 = 0xffffffffu;
     long pm1 = 0;                                    // OUT32: pixel index of tile g - 1 (-1: none)
     bool pv1 = false;
     u32x4 rres0 = {0, 0, 0, 0}, rres1 = {0, 0, 0, 0};   // shortcut chunks of tile g - 2
@@ -508,6 +523,10 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
         const int kh = ks <= 4 ? 0 : ks <= 8 ? 1 : 2;
         const unsigned base = ks == 4 ? (hi ? A1 - 32u : A0 + 256u) : ks == 13 ? A2 + 256u - (hi ? 32u : 0u) : kh == 0 ? A0 : kh == 1 ? A1 : A2;
         const int imm = (ks == 4 || ks == 13 ? 0 : 2 * (32 * ks - 144 * kh)) + ii * 16 * WS_PIX;
+        if (ABL & 8) {
+            asm volatile("" : "+v"(xf[slot]) : "v"(base));
+            return;
+        }
         xf[slot] = *(const __attribute__((address_space(3))) half8*)(size_t)(base + (unsigned)imm);
     };
     // B phase: value v (0..11) of tile g - 1
@@ -517,7 +536,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
         const int j = v >> 2, e = v & 3;
         if (e == 0) bj = *(const floatx4*)(bias_p + j * 16 + cq);
         float x = pacc[j][e] + bj[e];    // the K steps in order on a zero accumulator, then the bias: the order of the kernel above
-        if (ACT) x = silu_w(x);
+        if (ACT && !(ABL & 16)) x = silu_w(x);
         bv[e] = x;
         if (e == 3) {
             if (OUT32) {
@@ -547,7 +566,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
     u32x4 cda, cdb;
     const auto c_read = [&](int c) {
         if (OUT32) return;
-        const unsigned char* const p = c ? sr1 : sr0;
+        const unsigned char* const p = stage_rd(c);
         cda = *(const u32x4*)p;
         if (RES) cdb = *(const u32x4*)(p + 16);
     };
@@ -569,7 +588,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
         } else {
             o = cda;
         }
-        const unsigned off = ob2 == 0xffffffffu ? 0xffffffffu : ob2 + (c ? oo1 : oo0);
+        const unsigned off = (ob2 + out_off(c)) | dead(c) | inv2;
         __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
     };
 
@@ -593,7 +612,10 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][j], xf[(G0 + ks) % 3], acc[j], 0, 0, 0);
+                if (ABL & 1)
+                    asm volatile("" : "+v"(acc[j]) : "v"(wreg[ks][j]), "v"(xf[(G0 + ks) % 3]));
+                else
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][j], xf[(G0 + ks) % 3], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0) {
                 if (RES && !OUT32) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rres0), "+v"(rres1) : "n"(DPREV));
@@ -606,8 +628,8 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
             }
             if (ks == 2) c_store(1);
             if (ks == 3 && RES && !OUT32) {   // shortcut chunks of tile g - 1 (drained in the next tile loop)
-                rres0 = ld16_asm(res_rsrc, rb1 == 0xffffffffu ? 0xffffffffu : rb1 + ro0);
-                rres1 = ld16_asm(res_rsrc, rb1 == 0xffffffffu ? 0xffffffffu : rb1 + ro1);
+                rres0 = ld16_asm(res_rsrc, (rb1 + res_off(0)) | inv1);
+                rres1 = ld16_asm(res_rsrc, (rb1 + res_off(1)) | dead(1) | inv1);
             }
             if (ks >= 2) b_value(ks - 2);
             if (ks >= 5 && (ks & 1) && ks <= 11) {
@@ -619,8 +641,8 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
         // tile g becomes tile g - 1
 #pragma unroll
         for (int j = 0; j < 3; ++j) pacc[j] = acc[j];
-        ob2 = ob1;
-        ob1 = ob0;
+        ob2 = ob1, inv2 = inv1;
+        ob1 = ob0, inv1 = 0u;
         rb1 = rb0;
         pm1 = pm0;
         pv1 = true;
@@ -640,7 +662,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
                 wait_vmw<OPS>();
             else
                 wait_vmw<OPS + AFTER>();
-            __builtin_amdgcn_s_barrier();
+            if (!(ABL & 64)) __builtin_amdgcn_s_barrier();
             const Pair pair = pair_of(2 * s + 6);
             const int y = y_base + 2 * s + r;
             const long m_row = ((long)img_row0 + y) * WS_W + xh * 80 + t0 * 16;
@@ -668,12 +690,12 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
         c_store(1);
         asm volatile("" ::: "memory");
         if (RES && !OUT32) {
-            rres0 = ld16_asm(res_rsrc, rb1 + ro0);
-            rres1 = ld16_asm(res_rsrc, rb1 + ro1);
+            rres0 = ld16_asm(res_rsrc, rb1 + res_off(0));
+            rres1 = ld16_asm(res_rsrc, (rb1 + res_off(1)) | dead(1));
         }
 #pragma unroll
         for (int v = 0; v < 12; ++v) b_value(v);
-        ob2 = ob1;
+        ob2 = ob1, inv2 = inv1;
         if (RES && !OUT32) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres0), "+v"(rres1));
         asm volatile("" ::: "memory");
         c_read(0);
@@ -697,7 +719,10 @@ constexpr int kNumWsOld = 2 * kNumStrips;
 struct WspVariant {
     int strip_rows, nsplit;
 };
-const WspVariant kWsp[] = {{160, 2}, {80, 2}, {40, 2}, {20, 2}, {10, 2}, {160, 1}, {40, 1}, {10, 1}};   // ids 12..19
+// ids 12..16.  (Measured at 256 images, us per launch without / with a shortcut: kernel above 442 / 533; two waves per SIMD,
+// strips of 160 / 80 / 40 / 20 / 10 rows 397 / 508, 413 / 520, 450 / 543, 481 / 588, 575 / 684; one wave per SIMD 453 / 573:
+// the tile-outer order alone buys nothing, the second wave per SIMD does.)
+const WspVariant kWsp[] = {{160, 2}, {80, 2}, {40, 2}, {20, 2}, {160, 1}};
 constexpr int kNumWsp = sizeof(kWsp) / sizeof(kWsp[0]);
 constexpr int kNumWs = kNumWsOld + kNumWsp;
 
@@ -736,6 +761,16 @@ void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
      conv_wsp_kernel<true, true, false, NS>,   conv_wsp_kernel<true, true, true, NS>}
     static const Kern pkernels[2][8] = {WSP_KERNELS(1), WSP_KERNELS(2)};
 #undef WSP_KERNELS
+#ifdef RMR_WSP_ABLATE
+#define WSP_ABL(M) {M, conv_wsp_kernel<true, false, false, 2, M>, conv_wsp_kernel<true, true, false, 2, M>}
+    struct AblK {
+        int mask;
+        Kern plain, res;
+    };
+    static const AblK abl[] = {WSP_ABL(1), WSP_ABL(2), WSP_ABL(4), WSP_ABL(8), WSP_ABL(16), WSP_ABL(32), WSP_ABL(64), WSP_ABL(38), WSP_ABL(54),
+                               WSP_ABL(17), WSP_ABL(63), WSP_ABL(9)};
+#undef WSP_ABL
+#endif
     static std::once_flag once;
     std::call_once(once, [] {
         for (const auto& row : kernels)
@@ -749,7 +784,19 @@ void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
     const int nj = piped ? 1 : variant < kNumStrips ? 1 : 3;
     const int nsplit = piped ? kWsp[variant - kNumWsOld].nsplit : 1;
     const int kidx = (a.act ? 4 : 0) + (a.res ? 2 : 0) + (a.out32 ? 1 : 0);
-    const Kern kernel = piped ? pkernels[nsplit - 1][kidx] : kernels[nj == 1 ? 0 : 1][kidx];
+    Kern kernel = piped ? pkernels[nsplit - 1][kidx] : kernels[nj == 1 ? 0 : 1][kidx];
+#ifdef RMR_WSP_ABLATE
+    if (const char* e = std::getenv("RMR_WSP_ABLATE")) {
+        const int m = std::atoi(e);
+        if (m && piped && nsplit == 2 && a.act && !a.out32) {
+            kernel = nullptr;
+            for (const AblK& k : abl)
+                if (k.mask == m) kernel = a.res ? k.res : k.plain;
+            if (!kernel) fail(RMR_ERR_INVALID_ARGUMENT, "conv_wsp: ablation mask %d is not compiled in", m);
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+    }
+#endif
     const int sr = piped ? kWsp[variant - kNumWsOld].strip_rows : kWsStripRows[variant % kNumStrips];
     const int grid = a.N * (a.H / sr);
     const double flops = a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;

@@ -159,6 +159,12 @@ def test_conv_weights_stationary(rmr):
     run_case(rmr, 1, 160, 160, 48, 48, 3, 1, True, True, tile=306, seed=94)    # 12-wave layout, 4 strips, residual
     run_case(rmr, 3, 6, 160, 48, 48, 3, 1, False, False, tile=311, seed=95)    # 12-wave layout, 2-row strips
     run_case(rmr, 1, 20, 160, 48, 41, 3, 1, True, False, tile=307, seed=96)    # 12-wave layout, padded channels
+    # ids 12..16: the pipelined kernel (conv_wsp_kernel: tile-outer, a tile's SiLU and drain under the next tiles' MFMAs);
+    # 12-15 two waves per SIMD (strips of 160 / 80 / 40 / 20 rows), 16 one wave per SIMD (160)
+    for v, rows in enumerate([160, 80, 40, 20, 160]):
+        run_case(rmr, 2, 160, 160, 48, 48, 3, 1, True, True, tile=312 + v, seed=100 + v)
+        run_case(rmr, 1, rows, 160, 48, 41, 3, 1, v % 2 == 0, False, tile=312 + v, seed=110 + v)   # one strip, padded channels
+    run_case(rmr, 3, 20, 160, 48, 48, 3, 1, False, True, tile=315, seed=120)    # H = 20: the strip is the image, rows above / below arrive as zeros
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 8, 80, 48), np.float32), np.zeros((48, 48, 3, 3), np.float32), None, 1, 1,
                    False, tile=300)  # W != 160
@@ -204,6 +210,26 @@ def test_conv_stem(rmr):
     with pytest.raises(rmr.InvalidArgument):
         rmr.conv2d(np.zeros((1, 16, 64, 3), np.float32), np.zeros((48, 3, 3, 3), np.float32), None, 1, 1,
                    False, tile=500)  # stride 1
+
+
+def test_conv_weights_stationary_f16_views(rmr, monkeypatch):
+    """The same layers through their PRODUCTION epilogues (RMR_CONV2D_OUT16: the f16 output view the network uses -- LDS
+    stages, 16-byte stores, the shortcut added in registers at the drain), old kernel and pipelined kernel: each within
+    the f16 rounding of the torch reference, and bit-identical to each other (same f32 operation order per value)."""
+    monkeypatch.setenv("RMR_CONV2D_OUT16", "1")
+    rng = np.random.default_rng(7)
+    for res in (False, True):
+        for silu in (True, False):
+            x = r16(rng.normal(0, 1, (2, 160, 160, 48)).astype(np.float32))
+            wt = r16((rng.normal(0, 1, (48, 48, 3, 3)) / np.sqrt(48 * 9)).astype(np.float32))
+            b = rng.normal(0, 0.5, 48).astype(np.float32)
+            r = r16(rng.normal(0, 1, (2, 160, 160, 48)).astype(np.float32)) if res else None
+            want = ref_conv(x, wt, b, 1, 1, silu, r)
+            outs = {t: rmr.conv2d(x, wt, b, 1, 1, silu, r, tile=t) for t in (300, 306, 312, 313, 314, 315, 316)}
+            for t, got in outs.items():
+                err = np.abs(got - want).max()
+                assert err <= 2e-3 * max(1.0, np.abs(want).max()), f"tile {t} res {res} silu {silu}: max err {err}"
+                assert np.array_equal(got, outs[300]), f"tile {t} res {res} silu {silu}: not bit-identical to tile 300"
 
 
 def test_conv_ws_stride2(rmr):
