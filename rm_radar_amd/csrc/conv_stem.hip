@@ -40,7 +40,10 @@ constexpr int ST_DMA = (ST_PATCH + 63) / 64;          // 18 DMA instructions
 constexpr int ST_NI = (ST_DMA + 3) / 4;               // per wave
 constexpr int ST_PATCH_BYTES = ST_DMA * 1024;
 constexpr int ST_OUT_BYTES = ST_TH * ST_TW * 96;
-constexpr int ST_LDS = ST_PATCH_BYTES + ST_OUT_BYTES;
+// round 4: the output stage ALIASES the patch (one more barrier per tile, after the last fragment read): 24.6 KB per
+// workgroup instead of 43 KB, so five or six tiles are resident per CU where LDS allowed three (the kernel is VALU-bound
+// at ~70 % VALU-busy with three waves per SIMD; registers now allow five)
+constexpr int ST_LDS = ST_PATCH_BYTES > ST_OUT_BYTES ? ST_PATCH_BYTES : ST_OUT_BYTES;
 constexpr int ST_LB_TABLES = (ST_PW + ST_PH) * 16;     // LB: column and row entries
 
 // v * rcp(1 + e^-v): the hardware reciprocal (1 ulp) instead of an IEEE division -- the epilogue's VALU
@@ -54,8 +57,11 @@ __device__ __forceinline__ void dma16s(u32x4 rsrc, unsigned lds_addr, unsigned v
                  : "memory");
 }
 
+// (amdgpu_waves_per_eu(3): a register budget of 168 makes hipcc keep the accumulators in ArchVGPRs -- with the default budget
+// of 512 it parks them in AccVGPRs and the epilogue pays one v_accvgpr_read per value, 48 per lane and tile, in a kernel
+// that is VALU-bound: 68-72 % VALU-busy in profiles/r04_pmc_first_layers.txt)
 template <bool LB>
-__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, const LetterboxDesc* __restrict__ descs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_stem_kernel(const ConvArgs a, const LetterboxDesc* __restrict__ descs,
                                                         int fill, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -182,11 +188,13 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, const 
     __syncthreads();
 
     // ---- wave w: output rows 2w, 2w + 1 of the tile, two 16-pixel fragments each ----------------
+    // the accumulators start at the bias (round 4: 48 adds per lane and tile less in the epilogue; the f32 sum is bias + taps
+    // instead of taps + bias, within the same half ulp of f32)
     floatx4 acc[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 3; ++j) acc[i][j] = floatx4{bias[j].x, bias[j].y, bias[j].z, bias[j].w};
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         int tap = 4 * ks + kg;
@@ -206,14 +214,14 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvArgs a, const 
     }
 
     // ---- epilogue: bias + SiLU, f16, through LDS so that stores are whole pixels ----------------
-    unsigned char* const stage = smem + ST_PATCH_BYTES;
+    __syncthreads();   // every wave has read its last patch fragment: the stage may overwrite the patch
+    unsigned char* const stage = smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 2 * wave + (i >> 1), c = (i & 1) * 16 + frow;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
-                          acc[i][j][3] + bias[j].w};
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (a.act) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = silu_s(v[e]);

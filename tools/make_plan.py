@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.pop("RMR_PLAN", None)
+os.environ.setdefault("RMR_TUNE_ROUNDS", "6")   # a committed plan deserves a longer run-off than a first call in the field
 import numpy as np  # noqa: E402
 
 import bench  # noqa: E402
