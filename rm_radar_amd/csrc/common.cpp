@@ -29,22 +29,23 @@ hipEvent_t Profiler::get_event() {
 void Profiler::push(const Pending& p) {
     std::lock_guard<std::mutex> lk(mu);
     pending.push_back(p);
-    if (!order_checked) {
-        order_checked = true;
-        if (const char* f = std::getenv("RMR_PROFILE_ORDER")) order_log = *f ? std::fopen(f, "a") : nullptr;
-    }
-    if (order_log) {
-        std::fprintf(order_log, "%d %s|%s|%.0f|%.0f\n", on, p.stage == 1 ? "car" : p.stage == 2 ? "armor" : "", p.name, p.flops, p.bytes);
-        std::fflush(order_log);
-    }
+    pending.back().level = on;
 }
 
 void Profiler::resolve() {
     std::lock_guard<std::mutex> lk(mu);
+    if (!order_checked) {
+        order_checked = true;
+        if (const char* f = std::getenv("RMR_PROFILE_ORDER")) order_log = *f ? std::fopen(f, "a") : nullptr;
+    }
     for (auto& p : pending) {
         (void)hipEventSynchronize(p.b);
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            // RMR_PROFILE_ORDER: every profiled launch in enqueue order with its own duration
+            if (order_log)
+                std::fprintf(order_log, "%d %s|%s|%.0f|%.0f|%.6f\n", p.level, p.stage == 1 ? "car" : p.stage == 2 ? "armor" : "", p.name, p.flops,
+                             p.bytes, ms);
             ProfEntry& e = stats[p.stage == 1 ? std::string("car|") + p.name : p.stage == 2 ? std::string("armor|") + p.name : std::string(p.name)];
             e.launches += 1;
             e.total_ms += ms;
@@ -55,6 +56,7 @@ void Profiler::resolve() {
         pool.push_back(p.b);
     }
     pending.clear();
+    if (order_log) std::fflush(order_log);
 }
 
 void Profiler::reset() {

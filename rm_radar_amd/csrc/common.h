@@ -131,9 +131,10 @@ struct Profiler {
     // the same shapes (batch 256: car chunk = armor chunk) can still be told apart.  Thread-local: the locate helper
     // thread's launches are never tagged.
     static thread_local int stage;
-    // RMR_PROFILE_ORDER=<file> (read once): every profiled launch is also appended to that file in enqueue order
-    // ("<level> <stage>|<name>|<flops>|<bytes>"), so that tools/pmc_traffic.py can give the k-th convolution dispatch of a
-    // rocprofv3 --pmc pass its layer (PMC rows carry kernel symbols only)
+    // RMR_PROFILE_ORDER=<file> (read once): every profiled launch is also appended to that file in enqueue order when its
+    // events are resolved ("<level> <stage>|<name>|<flops>|<bytes>|<ms>"), so that tools/pmc_traffic.py can give the k-th
+    // convolution dispatch of a rocprofv3 --pmc pass its layer (PMC rows carry kernel symbols only) and tools/make_plan.py
+    // can read every layer's own time inside the network
     FILE* order_log = nullptr;
     bool order_checked = false;
     std::mutex mu;
@@ -142,6 +143,7 @@ struct Profiler {
         const char* name;
         double flops, bytes;
         int stage;
+        int level = 0;   // prof.on when it was pushed
     };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;

@@ -51,7 +51,7 @@ def step_order(path):
     rows = []
     for line in open(path):
         level, rest = line.rstrip("\n").split(" ", 1)
-        stage, name, flops, nbytes = rest.split("|")
+        stage, name, flops, nbytes = rest.split("|")[:4]
         if level == "2" and float(flops) > 0:
             rows.append((stage, name, float(flops), float(nbytes)))
     names = [r[1] for r in rows]
