@@ -59,7 +59,7 @@ KERNEL_OF_TAG = {"g": "conv_t32_kernel (csrc/conv_t32.hip)", "m": "conv_g32_kern
                  "v": "conv_ws_s2_kernel (csrc/conv_ws_s2.hip)", "d": "conv_dma_kernel (csrc/conv_dma.hip)",
                  "t": "conv_igemm_kernel (csrc/conv_igemm.hip)", "h": "conv_halo_kernel (csrc/conv_halo.hip)",
                  "x": "conv_direct_kernel (csrc/conv_direct.hip)", "f": "conv_t32f8_kernel (csrc/conv_t32f8.hip)",
-                 "s": "conv_stem_kernel (csrc/conv_stem.hip)"}
+                 "s": "conv_stem_kernel (csrc/conv_stem.hip)", "b": "conv_wsf_kernel (csrc/conv_ws.hip: a fused C2f bottleneck)"}
 
 
 def instantiation_of(layer_name):

@@ -310,6 +310,15 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
             if (!conv_direct_supported(a, tile - 400))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: direct tile %d cannot run this layer", tile - 400);
             launch_conv_direct(ctx, ctx.stream, a, tile - 400);
+        } else if (tile >= 340 && tile < 400) {
+            // conv_wsf (340..): a whole bottleneck, out = x + SiLU(conv(SiLU(conv(x)))), here with ONE filter for both
+            // convolutions (the test restates exactly that); `residual` is not used -- the shortcut is the input
+            a.wt2 = a.wt;
+            a.bias2 = a.bias;
+            a.res = nullptr;
+            if (!conv_wsf_supported(a, tile - 340))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: fused-bottleneck variant %d cannot run this layer", tile - 340);
+            launch_conv_wsf(ctx, ctx.stream, a, tile - 340);
         } else if (tile >= 300) {
             if (!conv_ws_supported(a, tile - 300))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: weights-stationary variant %d cannot run this layer", tile - 300);
@@ -529,6 +538,14 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
                 if (tile - 600 >= conv_ws_s2_num_variants() || !conv_ws_s2_supported(a, tile - 600))
                     fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: ws_s2 variant %d cannot run this layer", tile - 600);
                 launch_conv_ws_s2(ctx, ctx.stream, a, tile - 600);
+            } else if (tile >= 340 && tile < 400) {   // the fused bottleneck: both convolutions (twice the FLOPs of the shape)
+                ConvArgs f = a;
+                f.wt2 = f.wt;
+                f.bias2 = f.bias;
+                f.res = nullptr;
+                if (tile - 340 >= conv_wsf_num_variants() || !conv_wsf_supported(f, tile - 340))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: fused-bottleneck variant %d cannot run this layer", tile - 340);
+                launch_conv_wsf(ctx, ctx.stream, f, tile - 340);
             } else if (tile >= 300 && tile < 400) {
                 if (tile - 300 >= conv_ws_num_variants() || !conv_ws_supported(a, tile - 300))
                     fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: ws variant %d cannot run this layer", tile - 300);

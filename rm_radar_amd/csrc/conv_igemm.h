@@ -45,6 +45,10 @@ struct ConvArgs {
     // slices per 32-channel chunk (pack_conv_weights_w1d)
     const __half* wt_w1d;
     unsigned wt_w1d_bytes;
+    // conv_wsf only (a fused C2f bottleneck, conv_ws.hip): the SECOND convolution's packed weights and bias; `in` is the
+    // bottleneck's input (and its shortcut), `out` the bottleneck's output, the hidden tensor lives in LDS
+    const __half* wt2;
+    const float* bias2;
     // conv_t32f8 only: the input quantised to e4m3 (rows of in8_cs bytes, zero beyond Cin), the weights as e4m3
     // LDS images with one scale per output channel (pack_conv_weights_t32f8)
     const unsigned char* in8;
@@ -98,6 +102,11 @@ void launch_conv_halo(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int tile);
 int conv_ws_num_variants();
 bool conv_ws_supported(const ConvArgs& a, int variant);  // variant < 0: any
 void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant);
+// a whole C2f bottleneck of that shape in one launch: out = in + SiLU(conv2(SiLU(conv1(in)))), both 3x3 / 48 -> 48 on
+// 160-wide maps (a.wt / a.bias, a.wt2 / a.bias2); the hidden tensor never leaves LDS.  Bit-identical to the two launches.
+int conv_wsf_num_variants();
+bool conv_wsf_supported(const ConvArgs& a, int variant);  // variant < 0: any
+void launch_conv_wsf(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant);
 // small-batch variant (conv_direct.hip): operands fetched from L2 in MFMA fragment shape, the K loop
 // split across the waves of a workgroup; Cin % 32 == 0
 int conv_direct_num_tiles();

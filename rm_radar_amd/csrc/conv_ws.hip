@@ -36,6 +36,7 @@ namespace rmr {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -712,6 +713,296 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
         run(std::integral_constant<int, 2>{});
 }
 
+// =====================================================================================================================
+// conv_wsf_kernel (round 4): a whole C2f bottleneck of this shape in ONE launch -- out = x + SiLU(conv2(SiLU(conv1(x)))) --
+// with the hidden tensor in LDS.  Why: the two launches move x in, h out, h in, x in again (the shortcut), y out = 5 tensors
+// of 629 MB at 256 images; with a shortcut the second launch runs at 4.5 TB/s of real traffic, and the ablation of
+// conv_wsp prices the stores of the first at 65 us and the input DMAs + shortcut loads of the second at ~150 us of a 885 us
+// pair.  Fused: x in once, y out once.
+//   * eight waves, two per SIMD: waves 0-3 hold the FIRST filter and compute hidden rows, waves 4-7 hold the SECOND and
+//     compute output rows three steps behind; a step is one image row (ten 16-pixel tiles per convolution: the conv1 waves of
+//     SIMDs 0-3 take 3, 3, 2, 2 of them, the conv2 waves 2, 2, 3, 3 -- five tiles per SIMD and step);
+//   * LDS: a ring of six x rows (DMA two steps ahead; row s - 1 doubles as the shortcut of the output row of step s), a ring
+//     of four hidden rows (written by conv1 in MFMA layout with the same zero edge pixels, read by conv2 as fragments), one
+//     f16 output tile per conv2 wave, bias vectors: 163 200 of 163 840 bytes;
+//   * hidden rows outside the image are zeros (conv2's padding), and a strip recomputes one hidden row above and below itself;
+//   * a wave runs tile by tile -- 42 MFMAs, then the tile's bias + SiLU (+ shortcut from the x ring, + drain through the
+//     stage for conv2) -- NOT software-pipelined as conv_wsp: with two filters' worth of code paths the carried accumulators
+//     spilled (230 registers in one attempt), and conv_wsp's own measurements say the overlap that matters is the other
+//     wave of the SIMD (one's epilogue beside the other's MFMAs), not the pipelining inside a wave;
+//   * one f32 operation order per value, as the two launches: K steps in order on a zero accumulator, + bias, SiLU, h rounded
+//     to f16 (what the unfused plan stores), ... + bias, SiLU, + (float)x, rounded to f16: bit-identical outputs.
+constexpr int WF_XSLOTS = 6, WF_HSLOTS = 4;
+constexpr int WF_STAGE = 1536;
+constexpr int WF_LDS = (WF_XSLOTS + WF_HSLOTS) * WS_ROW + 4 * WF_STAGE + 1024 + 512;
+static_assert(WF_LDS <= 160 * 1024, "the fused bottleneck's rings do not fit the LDS");
+
+template <bool OUT32>
+__global__ __launch_bounds__(512) void conv_wsf_kernel(const ConvArgs a, const int strip_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave & 3;            // SIMD
+    const int role = wave >> 2;        // 0: conv1 (x -> hidden), 1: conv2 (hidden -> out)
+    const bool three = role == 0 ? g < 2 : g >= 2;                       // three tiles per step (else two)
+    const int t0 = role == 0 ? (g < 2 ? 3 * g : 6 + 2 * (g - 2)) : (g < 2 ? 2 * g : 4 + 3 * (g - 2));
+    const int frow = lane & 15, kg = lane >> 4;
+    const bool hi = kg >= 2;
+    const int px = lane & 15, cq = (lane >> 4) * 4;
+
+    const int strips = a.H / strip_rows;
+    const int img = blockIdx.x / strips;
+    const int y_base = (blockIdx.x % strips) * strip_rows;
+    const int steps = strip_rows + 3;   // hidden rows y_base - 1 .. y_base + strip_rows at steps 0 .. strip_rows + 1; output row y_base + s - 3 at step s
+
+    const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu), sgpr(a.in_bytes), sgpr(0x00020000u)};
+    const unsigned hid0 = lds0 + WF_XSLOTS * WS_ROW;
+    unsigned char* const stage_p = smem + (WF_XSLOTS + WF_HSLOTS) * WS_ROW + g * WF_STAGE;
+    const unsigned scratch = sgpr(lds0 + (WF_XSLOTS + WF_HSLOTS) * WS_ROW + 4 * WF_STAGE);
+    float* const bias_p = (float*)(smem + (WF_XSLOTS + WF_HSLOTS) * WS_ROW + 4 * WF_STAGE + 1024) + role * 64;
+
+    for (int i = tid; i < (WF_XSLOTS + WF_HSLOTS) * 2 * (WS_PIX / 16); i += 512) {
+        const int slot = i / (2 * (WS_PIX / 16));
+        const int rem = i % (2 * (WS_PIX / 16));
+        const int side = rem / (WS_PIX / 16), c16 = rem % (WS_PIX / 16);
+        *(u32x4*)(smem + slot * WS_ROW + side * (WS_W + 1) * WS_PIX + c16 * 16) = u32x4{0, 0, 0, 0};
+    }
+    if (tid < WS_C) {
+        float* const b0 = (float*)(smem + (WF_XSLOTS + WF_HSLOTS) * WS_ROW + 4 * WF_STAGE + 1024);
+        b0[tid] = a.bias[tid];
+        b0[64 + tid] = a.bias2[tid];
+    }
+    __syncthreads();
+
+    half8 wreg[WS_KSTEPS][3];
+    {
+        const _Float16* const w = (const _Float16*)(role ? a.wt2 : a.wt);
+#pragma unroll
+        for (int ks = 0; ks < WS_KSTEPS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wreg[ks][j] = *(const half8*)(w + (size_t)(j * 16 + frow) * a.Kp + ks * 32 + kg * 8);
+#pragma unroll
+        for (int ks = 0; ks < WS_KSTEPS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(wreg[ks][j]));
+    }
+
+    // ---- x rows: one row per step, 15 DMA instructions over 8 waves (slot q = wave + 8 j); relative row rx (0 = y_base - 2) in ring slot rx % 6
+    const int img_row0 = img * a.H;
+    const unsigned row_bytes = (unsigned)(WS_W * a.in_cs * 2);
+    const auto issue_row = [&](int rx) {
+        const int gy = y_base - 2 + rx;
+        const unsigned live = (gy >= 0 && gy < a.H && rx <= strip_rows + 3) ? 0xffffffffu : 0u;
+        const unsigned rowoff = (unsigned)(img_row0 + gy) * row_bytes;
+        const unsigned slot = lds0 + (unsigned)(rx % WF_XSLOTS) * WS_ROW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = wave + 8 * j;                       // wave-uniform
+            const unsigned q_ok = q < WS_DMA_ROW ? 0xffffffffu : 0u;
+            unsigned ln = (unsigned)lane;
+            asm volatile("" : "+v"(ln));                      // recomputed here, twice per step, instead of living in registers
+            const unsigned c = (unsigned)(q % WS_DMA_ROW) * 64u + ln;
+            const unsigned goff = ((c / 6u) * (unsigned)a.in_cs + (unsigned)a.in_co + (c % 6u) * 8u) * 2u;
+            const unsigned off = (goff + rowoff) | ~(live & q_ok);
+            const unsigned dst = (q_ok & (slot + (unsigned)(WS_PIX + (q % WS_DMA_ROW) * 1024))) | (~q_ok & scratch);
+            dma16w(in_rsrc, sgpr(dst), off);
+        }
+    };
+    issue_row(0);
+    issue_row(1);
+    issue_row(2);
+    issue_row(3);
+
+    const unsigned lane_off = (unsigned)(frow * WS_PIX + kg * 16 + t0 * 16 * WS_PIX);
+    // this lane's values of a tile in a ring row / in the stage: pixel px (+ the zero edge pixel), channels j * 16 + cq ..
+    const unsigned mf_off = (unsigned)((1 + t0 * 16 + px) * WS_PIX + cq * 2);
+    unsigned char* const sw = stage_p + px * 96 + cq * 2;
+    const int c0 = lane, c1 = (64 + lane) % 96;
+    const unsigned pq = (unsigned)((c0 / 6) | ((c0 % 6) << 4) | ((c1 / 6) << 8) | ((c1 % 6) << 12) | (lane >= 32 ? 1 << 16 : 0));
+    const auto pqv = [&]() {
+        unsigned q = pq;
+        asm volatile("" : "+v"(q));
+        return q;
+    };
+    const auto cp = [&](int c) { return (pqv() >> (c ? 8 : 0)) & 15u; };
+    const auto cqq = [&](int c) { return (pqv() >> (c ? 12 : 4)) & 15u; };
+    const auto dead = [&](int c) { return c ? 0u - ((pqv() >> 16) & 1u) : 0u; };
+    const unsigned out_pitch2 = (unsigned)a.out_cs * 2u, out_co2 = (unsigned)a.out_co * 2u;
+    const auto out_off = [&](int c) { return cp(c) * out_pitch2 + out_co2 + cqq(c) * 16u; };
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, OUT32 ? 0u : 0xfffffff0u, 0x00020000);
+
+    // fragment reads run PF K steps ahead of their MFMAs: a K step is only three MFMAs (51 cycles) here, and with two K
+    // steps of distance the wave waited for LDS at every step (measured: 9 500 cycles per row against 3 360 of MFMA work)
+#ifndef RMR_WSF_PF
+#define RMR_WSF_PF 4
+#endif
+    constexpr int PF = RMR_WSF_PF, XR = PF + 1;
+    floatx4 acc[3];
+    half8 xf[XR];
+    unsigned A0 = 0, A1 = 0, A2 = 0;   // this lane's fragment address in the three ring rows a step reads
+    const auto read_frag = [&](int ii, int ks, int slot) {
+        const int kh = ks <= 4 ? 0 : ks <= 8 ? 1 : 2;
+        const unsigned base = ks == 4 ? (hi ? A1 - 32u : A0 + 256u) : ks == 13 ? A2 + 256u - (hi ? 32u : 0u) : kh == 0 ? A0 : kh == 1 ? A1 : A2;
+        const int imm = (ks == 4 || ks == 13 ? 0 : 2 * (32 * ks - 144 * kh)) + ii * 16 * WS_PIX;
+        xf[slot] = *(const __attribute__((address_space(3))) half8*)(size_t)(base + (unsigned)imm);
+    };
+    // the 42 MFMAs of tile ii of this wave's step (T tiles): fragments two K steps ahead, into the next tile where there is one
+    const auto k_loop = [&](auto II, auto TT) {
+        constexpr int ii = decltype(II)::value, T = decltype(TT)::value;
+        constexpr int G0 = ii * WS_KSTEPS;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < WS_KSTEPS; ++ks) {
+            if (ks + PF < WS_KSTEPS)
+                read_frag(ii, ks + PF, (G0 + ks + PF) % XR);
+            else if (ii + 1 < T)
+                read_frag(ii + 1, ks + PF - WS_KSTEPS, (G0 + ks + PF) % XR);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ks][j], xf[(G0 + ks) % XR], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ================= conv1: hidden row of step s -> hidden ring (f16, what the two-launch plan stores) =================
+    unsigned hrow = 0;           // LDS address of this lane's values of tile 0 of the wave in the hidden row being written
+    float hmask = 1.f;           // 0: the hidden row lies outside the image (conv2 must read zeros there)
+    const auto conv1_tile = [&](int tile) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const floatx4 bj = *(const floatx4*)(bias_p + j * 16 + cq);
+            union {
+                u32x2w v;
+                _Float16 h[4];
+            } o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.h[e] = (_Float16)(silu_w(acc[j][e] + bj[e]) * hmask);
+            *(__attribute__((address_space(3))) u32x2w*)(size_t)(hrow + (unsigned)(tile * 16 * WS_PIX + j * 32)) = o.v;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const auto conv1_step = [&](auto TT) {
+        constexpr int T = decltype(TT)::value;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) read_frag(0, p, p);
+        k_loop(std::integral_constant<int, 0>{}, TT);
+        conv1_tile(0);
+        k_loop(std::integral_constant<int, 1>{}, TT);
+        conv1_tile(1);
+        if constexpr (T > 2) {
+            k_loop(std::integral_constant<int, 2>{}, TT);
+            conv1_tile(2);
+        }
+    };
+
+    // ================= conv2: output row of step s: + bias, SiLU, + x (from the x ring), f16, through the stage =================
+    const auto conv2_tile = [&](int tile, unsigned xres, unsigned ob, long pm) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const floatx4 bj = *(const floatx4*)(bias_p + j * 16 + cq);
+            union {
+                u32x2w v;
+                _Float16 h[4];
+            } rr, o;
+            rr.v = *(const __attribute__((address_space(3))) u32x2w*)(size_t)(xres + (unsigned)(tile * 16 * WS_PIX + j * 32));
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_w(acc[j][e] + bj[e]) + (float)rr.h[e];
+            if (OUT32) {
+                *(float4*)(a.out32 + (pm + tile * 16 + px) * a.out_cs + a.out_co + j * 16 + cq) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.h[e] = (_Float16)v[e];
+                *(u32x2w*)(sw + j * 32) = o.v;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one channel tile at a time: the scheduler otherwise keeps all twelve values live
+        }
+        if (OUT32) return;
+        asm volatile("" ::: "memory");
+        const unsigned obt = ob + (unsigned)tile * (unsigned)(16 * a.out_cs * 2);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const u32x4 d = *(const u32x4*)(stage_p + cp(c) * 96u + cqq(c) * 16u);
+            __builtin_amdgcn_raw_buffer_store_b128(d, out_rsrc, (obt + out_off(c)) | dead(c), 0, 0);
+        }
+        asm volatile("" ::: "memory");
+    };
+    const auto conv2_step = [&](auto TT, unsigned xres, unsigned ob, long pm) {
+        constexpr int T = decltype(TT)::value;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) read_frag(0, p, p);
+        k_loop(std::integral_constant<int, 0>{}, TT);
+        conv2_tile(0, xres, ob, pm);
+        k_loop(std::integral_constant<int, 1>{}, TT);
+        conv2_tile(1, xres, ob, pm);
+        if constexpr (T > 2) {
+            k_loop(std::integral_constant<int, 2>{}, TT);
+            conv2_tile(2, xres, ob, pm);
+        }
+    };
+
+    for (int s = 0; s < steps; ++s) {
+        // the x row conv1 reads last in this step (rx = s + 2) was issued at the start of step s - 2 (or by the prologue); the
+        // instructions issued since: the two row DMAs of step s - 1 and, on the conv2 waves, two stores per tile of steps
+        // s - 2 and s - 1 (they store from step 3 on)
+        if (role == 0 || s <= 3)
+            wait_vmw<2>();
+        else if (s == 4) {
+            if (three)
+                wait_vmw<2 + 6>();
+            else
+                wait_vmw<2 + 4>();
+        } else {
+            if (three)
+                wait_vmw<2 + 12>();
+            else
+                wait_vmw<2 + 8>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden-row writes (and ring reads) of the step before
+        __builtin_amdgcn_s_barrier();
+        issue_row(s + 4);   // into the slot of row s - 2, the shortcut row of step s - 1
+#ifdef RMR_WSF_STAGGER
+        if (role == 1) __builtin_amdgcn_s_sleep(RMR_WSF_STAGGER);   // experiment: the two waves of a SIMD half a tile out of phase
+#endif
+        // (opaque copies: the optimiser otherwise keeps "lane offset + slot base" for every slot and tile as induction variables
+        // across the step loop -- twenty-odd registers this kernel does not have)
+        unsigned lane_off_s = lane_off, mf_off_s = mf_off;
+        asm volatile("" : "+v"(lane_off_s), "+v"(mf_off_s));
+        if (role == 0) {
+            if (s <= strip_rows + 1) {
+                const int hr = y_base - 1 + s;
+                hmask = hr >= 0 && hr < a.H ? 1.f : 0.f;
+                A0 = lds0 + (unsigned)((s + 0) % WF_XSLOTS) * WS_ROW + lane_off_s;
+                A1 = lds0 + (unsigned)((s + 1) % WF_XSLOTS) * WS_ROW + lane_off_s;
+                A2 = lds0 + (unsigned)((s + 2) % WF_XSLOTS) * WS_ROW + lane_off_s;
+                hrow = hid0 + (unsigned)(s % WF_HSLOTS) * WS_ROW + mf_off_s;
+                if (three)
+                    conv1_step(std::integral_constant<int, 3>{});
+                else
+                    conv1_step(std::integral_constant<int, 2>{});
+            }
+        } else if (s >= 3) {
+            const int y = y_base + s - 3;
+            A0 = hid0 + (unsigned)((s - 3) % WF_HSLOTS) * WS_ROW + lane_off_s;
+            A1 = hid0 + (unsigned)((s - 2) % WF_HSLOTS) * WS_ROW + lane_off_s;
+            A2 = hid0 + (unsigned)((s - 1) % WF_HSLOTS) * WS_ROW + lane_off_s;
+            const unsigned xres = lds0 + (unsigned)((s - 1) % WF_XSLOTS) * WS_ROW + mf_off_s;
+            const long m_row = ((long)img_row0 + y) * WS_W + t0 * 16;
+            const unsigned ob = OUT32 ? 0u : (unsigned)(m_row * a.out_cs * 2);
+            if (three)
+                conv2_step(std::integral_constant<int, 3>{}, xres, ob, m_row);
+            else
+                conv2_step(std::integral_constant<int, 2>{}, xres, ob, m_row);
+        }
+    }
+    wait_vmw<0>();
+}
+
 // variant = strip height x wave layout (NJ = 1 for ids 0..5, NJ = 3 for ids 6..11); 12..: the pipelined kernel
 const int kWsStripRows[] = {40, 20, 10, 8, 4, 2};
 constexpr int kNumStrips = sizeof(kWsStripRows) / sizeof(kWsStripRows[0]);
@@ -726,7 +1017,54 @@ const WspVariant kWsp[] = {{160, 2}, {80, 2}, {40, 2}, {20, 2}, {160, 1}};
 constexpr int kNumWsp = sizeof(kWsp) / sizeof(kWsp[0]);
 constexpr int kNumWs = kNumWsOld + kNumWsp;
 
+const int kWsfStripRows[] = {160, 80, 40, 20};   // conv_wsf variants
+constexpr int kNumWsf = sizeof(kWsfStripRows) / sizeof(kWsfStripRows[0]);
+
 }  // namespace
+
+int conv_wsf_num_variants() { return kNumWsf; }
+
+bool conv_wsf_supported(const ConvArgs& a, int variant) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || !a.act || a.pre || a.in_slab_c || a.out_slab_c) return false;
+    if (a.Cin != WS_C || a.Cout_pad != WS_C || a.W != WS_W || a.Wo != a.W || a.Ho != a.H) return false;
+    if (a.Kp < WS_KSTEPS * 32 || (!a.out32 && !a.out) || !a.wt2 || !a.bias2) return false;
+    if (variant < 0) return a.H % 2 == 0;
+    return variant < kNumWsf && a.H % kWsfStripRows[variant] == 0;
+}
+
+void launch_conv_wsf(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant) {
+    if (variant < 0 || variant >= kNumWsf) fail(RMR_ERR_INVALID_ARGUMENT, "conv_wsf: variant %d out of range", variant);
+    if (!conv_wsf_supported(a, variant)) fail(RMR_ERR_LOGIC, "conv_wsf: layer pair not supported by variant %d", variant);
+    if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8) fail(RMR_ERR_LOGIC, "conv_wsf: misaligned view");
+    if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull) fail(RMR_ERR_LOGIC, "conv_wsf: input view size not set or larger than 3.75 GiB");
+    if (!a.out32 && (double)a.M * a.out_cs * 2 >= 4.0e9) fail(RMR_ERR_LOGIC, "conv_wsf: output view of 4 GB or more (32-bit store offsets)");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)conv_wsf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wsf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    const int sr = kWsfStripRows[variant];
+    const int grid = a.N * (a.H / sr);
+    // both convolutions; algorithmic bytes: x in, y out, two filters (the hidden tensor and the shortcut read never reach HBM)
+    const double flops = a.flops > 0 ? a.flops : 2.0 * 2.0 * a.M * (double)a.Cout_pad * a.K;
+    const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + 2.0 * a.Cout_pad * a.K);
+    static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
+    static std::mutex name_mu;
+    static std::map<std::string, std::string> names;
+    const char* pname = "conv_igemm_f16";
+    if (per_layer && ctx.prof.on) {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "conv n%d M%d N%d K%d k%d s%d x2 b%d", a.N, a.M, a.Cout_pad, a.K, a.KH, a.stride, variant);
+        std::lock_guard<std::mutex> lk(name_mu);
+        pname = names.emplace(buf, buf).first->second.c_str();
+    }
+    ProfScope ps(ctx.prof, stream, pname, flops, bytes);
+    if (a.out32)
+        conv_wsf_kernel<true><<<grid, 512, WF_LDS, stream>>>(a, sr);
+    else
+        conv_wsf_kernel<false><<<grid, 512, WF_LDS, stream>>>(a, sr);
+    RMR_HIP(hipGetLastError());
+}
 
 int conv_ws_num_variants() { return kNumWs; }
 

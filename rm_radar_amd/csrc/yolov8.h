@@ -98,6 +98,11 @@ class Yolov8 {
         size_t q_out_off = 0;
         int q_out_pitch = 0;
         int stride = 1, act = 1;
+        // a C2f bottleneck of the conv_wsf shape (two 3x3 / 48 -> 48 convolutions on 160-wide maps, shortcut = the first one's
+        // input, hidden tensor read by nobody else): this op is the FIRST convolution, fuse_with the index of the second.  A
+        // tuned choice of 340.. for this op runs both in one launch (conv_wsf: the hidden tensor stays in LDS); the second op
+        // then carries the choice kFusedAway and launches nothing
+        int fuse_with = -1;
         // OP_HEAD
         View box, cls;
         int head_stride = 0, a_off = 0;
@@ -134,7 +139,10 @@ class Yolov8 {
     bool pw_can(int K, int N, int h, int w, bool pre) const;
     void run_op(hipStream_t s, int op_index, int chunk_n, size_t img_base);
     ConvArgs conv_args(int op_index, int chunk_n, size_t img_base);
-    int tune_conv(hipStream_t s, const ConvArgs& a);
+    int tune_conv(hipStream_t s, const ConvArgs& a, float* best_ms_out = nullptr);
+    ConvArgs fused_args(int op_index, int n, size_t img0);   // ConvArgs of a fused bottleneck (op_index = its first convolution)
+    static constexpr int kFusedAway = 399;
+    std::map<std::pair<int, int>, float> tuned_ms_;   // the tuner's time of the first convolution of a fusable pair
 
     DeviceCtx& ctx_;
     int nc_, in_w_, in_h_, max_batch_, chunk_;

@@ -232,6 +232,38 @@ def test_conv_weights_stationary_f16_views(rmr, monkeypatch):
                 assert np.array_equal(got, outs[300]), f"tile {t} res {res} silu {silu}: not bit-identical to tile 300"
 
 
+def test_fused_bottleneck_matches_torch_and_the_two_launches(rmr, monkeypatch):
+    """conv_wsf (ids 340..): out = x + SiLU(conv(SiLU(conv(x) + b)) + b), 3x3 / 48 -> 48 on 160-wide maps, one launch with the
+    hidden tensor in LDS (rmr_conv2d runs it with one filter for both convolutions).  Against torch with the hidden tensor
+    rounded to f16 where the two-launch plan stores it; and bit-identical to those two launches through their f16 views."""
+    rng = np.random.default_rng(11)
+    for n, h, cout in ((2, 160, 48), (3, 40, 48), (1, 20, 41)):
+        x = r16(rng.normal(0, 1, (n, h, 160, 48)).astype(np.float32))
+        wt = r16((rng.normal(0, 1, (cout, 48, 3, 3)) / np.sqrt(48 * 9)).astype(np.float32))
+        if cout < 48:   # the second convolution consumes the first's output: pad the filter to 48 x 48 by hand
+            wt = np.concatenate([wt, np.zeros((48 - cout, 48, 3, 3), np.float32)])
+        b = rng.normal(0, 0.5, 48).astype(np.float32)
+        hid = r16(ref_conv(x, wt, b, 1, 1, True, None))
+        want = ref_conv(hid, wt, b, 1, 1, True, x)
+        for v, rows in enumerate([160, 80, 40, 20]):
+            if h % rows:
+                continue
+            got = rmr.conv2d(x, wt, b, 1, 1, True, None, tile=340 + v)      # f32 view
+            err = np.abs(got - want).max()
+            assert err <= 2e-3 * max(1.0, np.abs(want).max()), f"variant {v} n {n} h {h}: max err {err}"
+    monkeypatch.setenv("RMR_CONV2D_OUT16", "1")
+    x = r16(rng.normal(0, 1, (2, 160, 160, 48)).astype(np.float32))
+    wt = r16((rng.normal(0, 1, (48, 48, 3, 3)) / np.sqrt(48 * 9)).astype(np.float32))
+    b = rng.normal(0, 0.5, 48).astype(np.float32)
+    hid = rmr.conv2d(x, wt, b, 1, 1, True, None, tile=312)        # first launch, f16 output
+    two = rmr.conv2d(hid, wt, b, 1, 1, True, x, tile=312)         # second launch with the shortcut
+    for v in range(4):
+        one = rmr.conv2d(x, wt, b, 1, 1, True, None, tile=340 + v)
+        assert np.array_equal(one, two), f"variant {v}: fused bottleneck differs from the two launches"
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 80, 48), np.float32), np.zeros((48, 48, 3, 3), np.float32), None, 1, 1, True, tile=340)  # W != 160
+
+
 def test_conv_ws_stride2(rmr):
     # conv_ws_s2.hip (ids 600..): 3x3 / stride 2, 48 -> 96 channels, 320-wide input; ring rows are
     # de-interleaved by column parity, each workgroup takes one half of the map's width

@@ -334,6 +334,52 @@ def test_network_on_the_gathered_kernels(rmr, packs, refs, images, oracle, monke
     assert sum(1 for t in tuned if 950 <= int(t[2]) < 980) >= 10
 
 
+def test_fused_bottlenecks_equal_the_two_launches(rmr, packs, images, monkeypatch, tmp_path):
+    """conv_wsf: the two 3x3 convolutions of a 48-channel C2f bottleneck (model.2) in one launch, the hidden tensor in LDS.
+    Same f32 operation order and the same f16 rounding of the hidden tensor as the two launches, so the network's output
+    is BIT-identical.  The two-launch plan is what the tuner produces by default; its four weights-stationary layers
+    are then re-pointed at the fused kernel in a pinned plan (every variant), which must reproduce the output bit for bit;
+    and left to itself the tuner must produce a consistent plan (a fused first layer <=> a skipped second layer)."""
+    import shutil
+    n = 32
+    batch = [images[i % 3] for i in range(n)]
+    pack = str(tmp_path / "armor_two.rmrw")
+    shutil.copy(packs[1], pack)
+    monkeypatch.delenv("RMR_FUSE_WS", raising=False)   # default: the tuner does not try the fused launch
+    monkeypatch.setenv("RMR_TUNE_ONLY", "300-339")    # the 48-channel layers on the weights-stationary family
+    det = rmr.Detector(pack, 12, (2592, 2048), n, conf_thresh=0.5)
+    want, _ = det.infer(batch)
+    det.close()
+    lines = open(pack + ".tune").read().splitlines()
+    ws = [i for i, l in enumerate(lines[1:], 1) if 300 <= int(l.split()[2]) < 340]
+    assert len(ws) == 4, [lines[i] for i in ws]           # model.2: two bottlenecks
+    monkeypatch.delenv("RMR_TUNE_ONLY")
+    for variant in range(4):   # a plan that names the fused kernel is honoured whatever RMR_FUSE_WS says
+        plan = str(tmp_path / f"fused{variant}.plan")
+        out = list(lines)
+        for k, i in enumerate(ws):
+            op, nn, _ = out[i].split()
+            out[i] = f"{op} {nn} {340 + variant if k % 2 == 0 else 399}"
+        open(plan, "w").write("\n".join(out) + "\n")
+        monkeypatch.setenv("RMR_PLAN", plan)
+        det = rmr.Detector(packs[1], 12, (2592, 2048), n, conf_thresh=0.5)
+        got, _ = det.infer(batch)
+        det.close()
+        assert np.array_equal(got, want), f"conv_wsf variant {variant}"
+    monkeypatch.delenv("RMR_PLAN")
+    monkeypatch.setenv("RMR_FUSE_WS", "1")             # the tuner may now take the fused launch where it measures it faster
+    pack2 = str(tmp_path / "armor_auto.rmrw")
+    shutil.copy(packs[1], pack2)
+    det = rmr.Detector(pack2, 12, (2592, 2048), n, conf_thresh=0.5)
+    got, _ = det.infer(batch)
+    got2, _ = det.infer(batch)       # the second call runs the plan the first one tuned
+    det.close()
+    tuned = [int(l.split()[2]) for l in open(pack2 + ".tune").read().splitlines()[1:]]
+    assert sum(1 for c in tuned if 340 <= c < 399) == tuned.count(399)
+    assert np.array_equal(got, got2)
+    _check_head(got[:3], want[:3], 2.0, 1e-2)         # another tuning, same network
+
+
 def test_interleaved_chunks_plan_still_matches(rmr, packs, refs, images, oracle, monkeypatch):
     """RMR_SLABS=0: every C2f keeps its chunks as channel slices of one wide buffer (the layout before
     conv_pw could address planar channel groups); the fallback for shapes conv_pw does not cover."""

@@ -55,6 +55,16 @@ def run_child(mode, pack, nc, n, dtype, env_extra, stderr_path=None, order_log="
         subprocess.check_call(cmd, env=env, stderr=err, stdout=subprocess.DEVNULL)
 
 
+def parse_fusions(log):
+    """'fuse layers A + B at N images: two launches X us, conv_wsf variant V Y us -> ...' -> {A: (B, V)} (op indices)"""
+    out = {}
+    for line in open(log):
+        m = re.match(r"fuse layers (\d+) \+ (\d+) at \d+ images: .* conv_wsf variant (-?\d+) ", line)
+        if m and int(m.group(3)) >= 0:
+            out[int(m.group(1))] = (int(m.group(2)), int(m.group(3)))
+    return out
+
+
 def parse_tuning(log):
     """'tune M.. N.. K.. k. s.: id:us id:us ... [id:us] ...  -> id (us)' per layer, in op order -> [(chosen, {id: us})]; a
     finalist's run-off time replaces its first-pass time."""
@@ -112,41 +122,61 @@ def plan_for(which, nc, n, dtype, work):
         if os.path.exists(stale):
             os.remove(stale)
     log = pack + ".tunelog"
-    run_child("tune", pack, nc, n, dtype, {"RMR_TUNE_VERBOSE": "1", "RMR_TUNE_ROUNDS": os.environ.get("RMR_TUNE_ROUNDS", "6")}, log)
+    # RMR_FUSE_WS=1: the library also times the fused launch of every fusable bottleneck (conv_wsf) and prints it; whether the
+    # plan takes it is decided below, inside the network
+    run_child("tune", pack, nc, n, dtype, {"RMR_TUNE_VERBOSE": "1", "RMR_TUNE_ROUNDS": os.environ.get("RMR_TUNE_ROUNDS", "6"),
+                                           "RMR_FUSE_WS": "1"}, log)
     header, ops = read_plan(pack + ".tune", n)
-    choices = [c for _, c in ops]
-    if n < 16:
-        return header, ops, choices, None
     tuned = parse_tuning(log)
     assert len(tuned) == len(ops), f"{which} n={n}: {len(tuned)} tuning records, {len(ops)} plan entries"
+    FUSED_AWAY = 399   # the second convolution of a fused bottleneck (conv_wsf, choice 340.. on the layer before): no launch
+    choices = [chosen for chosen, _, _ in tuned]          # the two-launch choices, whatever the library then decided about fusing
+    if n < 16:
+        return header, ops, choices, None
+    index_of = {op: k for k, (op, _) in enumerate(ops)}
+    fusions = {index_of[a]: (index_of[b], v) for a, (b, v) in parse_fusions(log).items()}
     alts = []
     for (chosen, times, _), c in zip(tuned, choices):
-        assert chosen == c
         near = sorted((us, cid) for cid, us in times.items() if us <= 1.08 * times[c] and cid != c)
         alts.append([c] + [cid for _, cid in near[:2]])
-    n_cfg = max(len(a) for a in alts)
+    n_cfg = max(2 if fusions else 1, max(len(a) for a in alts))
     measured = []   # per config: per-op in-network ms
     names = None
     for j in range(n_cfg):
         cfg = [a[j] if j < len(a) else a[0] for a in alts]
+        if j == 1:                                        # the second plan runs every fusable bottleneck fused
+            for ka, (kb, v) in fusions.items():
+                cfg[ka], cfg[kb] = 340 + v, FUSED_AWAY
+        launched = [k for k, c in enumerate(cfg) if c != FUSED_AWAY]
         plan = pack + f".plan{j}"
         write_plan(plan, header, n, ops, cfg)
         order = pack + f".order{j}"
         if os.path.exists(order):
             os.remove(order)
         run_child("time", pack, nc, n, dtype, {"RMR_PLAN": plan, "RMR_PROFILE_ORDER": order, "RMR_PROFILE_LAYERS": "1"}, None, order)
-        ms, nm = per_op_times(order, len(ops))
+        ms_l, nm_l = per_op_times(order, len(launched))
+        ms, nm = [0.0] * len(ops), [""] * len(ops)
+        for k, t, name in zip(launched, ms_l, nm_l):
+            ms[k], nm[k] = t, name
         measured.append((cfg, ms))
         names = names or nm
     final, report = [], []
     for k in range(len(ops)):
         cands = {}
         for cfg, ms in measured:
-            cands[cfg[k]] = min(cands.get(cfg[k], 1e30), ms[k])
+            if cfg[k] < 340 or cfg[k] > FUSED_AWAY:       # fused launches are judged pair-wise below
+                cands[cfg[k]] = min(cands.get(cfg[k], 1e30), ms[k])
         best = min(cands, key=cands.get)
         final.append(best)
         if best != choices[k]:
             report.append(f"  op {ops[k][0]:3d} {names[k]:48s}: tuner {choices[k]} ({cands[choices[k]] * 1e3:.1f} us in the network) -> {best} ({cands[best] * 1e3:.1f} us)")
+    for ka, (kb, v) in fusions.items():                   # a bottleneck: its two best launches against the fused one, both in the network
+        two = min(ms[ka] for cfg, ms in measured if cfg[ka] == final[ka]) + min(ms[kb] for cfg, ms in measured if cfg[kb] == final[kb])
+        one = measured[1][1][ka]
+        verdict = "fused" if one < two else "two launches"
+        report.append(f"  ops {ops[ka][0]} + {ops[kb][0]} (bottleneck): two launches {two * 1e3:.1f} us, conv_wsf variant {v} {one * 1e3:.1f} us in the network -> {verdict}")
+        if one < two:
+            final[ka], final[kb] = 340 + v, FUSED_AWAY
     base = sum(measured[0][1])
     picked = sum(min(ms[k] for cfg, ms in measured if cfg[k] == final[k]) for k in range(len(ops)))
     print(f"{which} {dtype} n={n}: in-network run-off over {n_cfg} plans changed {len(report)} of {len(ops)} layers; conv time {base:.3f} -> {picked:.3f} ms")
