@@ -113,7 +113,9 @@ int rmr_stream_owner(int stream, int world);
 int rmr_streams_of_rank(int n_streams, int rank, int world, int* out, int cap);
 /* rank 0 creates the id; the host application hands it to the other ranks (env, file, MPI, socket ...) */
 rmr_status rmr_comm_unique_id(int transport, char* id /* [RMR_COMM_ID_BYTES] */);
-/* collective over all ranks (RCCL: ncclCommInitRank on `device`) */
+/* collective over all ranks (RCCL: ncclCommInitRank on `device`; FILE: rank 0 hands every rank the communicator's epoch in
+ * a token handshake through the directory, so a second communicator on one path -- a restarted rank, a caller-supplied
+ * directory -- never reads what an earlier one left behind; returns when every rank has joined, 120 s at most) */
 rmr_status rmr_comm_create(int transport, int device, int rank, int world, const char* id, rmr_comm** out);
 void rmr_comm_destroy(rmr_comm* comm);
 /* every rank contributes n records (the same n on every rank); all[world][n] on every rank on return */

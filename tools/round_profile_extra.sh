@@ -1,16 +1,17 @@
 #!/bin/bash
-# Round-3 artefacts beside tools/round_profile.sh: the power-limit microbenchmarks, counters and clocks of the
-# 3x3 kernels on one layer, the fp8 plan's profile and bench line.  usage: bash tools/round_profile_extra.sh <tag>
+# Artefacts beside tools/round_profile.sh: the power-limit microbenchmarks, counters and clocks of the 3x3 kernels on
+# one layer, the fp8 plan's profile and bench lines, configs[3].  usage: bash tools/round_profile_extra.sh <tag> [round]
 set -u
 TAG=${1:-v1}
+R=${2:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out/round
 mkdir -p $OUT
-hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_power.hip -o /tmp/mfma_power && /tmp/mfma_power > $OUT/r03_mfma_power_f16.txt
-hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_fp8_power.hip -o /tmp/mfma_fp8 && /tmp/mfma_fp8 > $OUT/r03_mfma_power_fp8.txt
-bash tools/conv_pmc.sh 256,40,40,192,192 800 conv_t32 > $OUT/r03_conv_t32_pmc.txt 2>&1
-bash tools/conv_pmc.sh 256,80,80,192,384,3,2 952 conv_g32 > $OUT/r03_conv_g32_pmc.txt 2>&1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/lds_dma_rate.hip -o /tmp/lds_dma && /tmp/lds_dma > $OUT/r03_lds_dma_rate.txt
+hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_power.hip -o /tmp/mfma_power && /tmp/mfma_power > $OUT/${R}_mfma_power_f16.txt
+hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_fp8_power.hip -o /tmp/mfma_fp8 && /tmp/mfma_fp8 > $OUT/${R}_mfma_power_fp8.txt
+bash tools/conv_pmc.sh 256,40,40,192,192 800 conv_t32 > $OUT/${R}_conv_t32_pmc.txt 2>&1
+bash tools/conv_pmc.sh 256,80,80,192,384,3,2 952 conv_g32 > $OUT/${R}_conv_g32_pmc.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/lds_dma_rate.hip -o /tmp/lds_dma && /tmp/lds_dma > $OUT/${R}_lds_dma_rate.txt
 {
   echo "# effective clock (GRBM_GUI_ACTIVE summed over 8 XCDs / duration: divide the printed GHz by 8) and MFMA-busy fraction"
   echo "# (printed fraction x 8) of one layer, M409600 N192 K1728, random operands unless noted"
@@ -34,8 +35,9 @@ bash tools/conv_pmc.sh 256,80,80,192,384,3,2 952 conv_g32 > $OUT/r03_conv_g32_pm
   BG=$!
   for i in 1 2 3 4 5; do sleep 2; rocm-smi --showpower --showmaxpower --showclocks 2>/dev/null | grep -E "Package Power|sclk" | tr "\n" " "; echo; done
   wait $BG
-} > $OUT/r03_conv_clock.txt 2>&1
-RMR_FP8=1 python tools/layer_profile.py 256 12 > $OUT/r03_layer_profile_b256_fp8_${TAG}.txt 2>&1
-python bench.py --config 4 --steps 5 --warmup 1 > $OUT/r03_bench_config4_fp8_${TAG}.json 2> $OUT/bench_fp8.log
-python bench.py --dtype fp8 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/r03_bench_b64_fp8_${TAG}.json 2>> $OUT/bench_fp8.log
-tail -c 700 $OUT/r03_bench_config4_fp8_${TAG}.json
+} > $OUT/${R}_conv_clock.txt 2>&1
+RMR_FP8=1 python tools/layer_profile.py 256 12 > $OUT/${R}_layer_profile_b256_fp8_${TAG}.txt 2>&1
+python bench.py --config 4 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/${R}_bench_config4_fp8_${TAG}.json 2> $OUT/bench_fp8.log
+python bench.py --config 3 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_config3_${TAG}.json 2>> $OUT/bench_fp8.log
+python bench.py --dtype fp8 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_b64_fp8_${TAG}.json 2>> $OUT/bench_fp8.log
+tail -c 700 $OUT/${R}_bench_config4_fp8_${TAG}.json
