@@ -185,19 +185,6 @@ class Yolov8 {
     };
     std::map<int, Graph> graphs_;
     int graph_max_batch_ = 8;
-    // Round 4 experiment, OFF by default (RMR_GRAPH_BRANCHES=1): the graph as a DAG instead of a chain.  capture_dag() records
-    // the ops on up to four streams by their real dependencies (byte ranges read / written, arena aliasing included), so the
-    // Detect head of a scale may run beside the rest of the neck and the box / class branches beside each other.  Measured
-    // (tools/latency_probe.py 4 200, same box, alternating): chain p50 2.52 / 2.55 ms, DAG 2.70 / 2.63 ms -- a graph's
-    // cross-branch dependencies cost more on this runtime than the 10-us kernels they would overlap, as side streams did.
-    struct Range {
-        int arena;          // 0 f16, 1 f32, 2 e4m3 arenas; 10 input canvas, 11 network output, 12 split-K workspace
-        size_t lo, hi;
-    };
-    void op_ranges(int op_index, int n, std::vector<Range>& rd, std::vector<Range>& wr) const;
-    void capture_dag(hipStream_t s, int batch, std::vector<hipEvent_t>& events);
-    bool graph_branches_ = false;
-    hipStream_t side_[3] = {nullptr, nullptr, nullptr};
     bool all_tuned(int n) const;
     // letterbox fused into the first layer (RMR_FUSE_LB=0 keeps the separate kernel)
     bool fuse_lb_ = true;

@@ -490,7 +490,6 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     if (const char* e = std::getenv("RMR_CHUNK")) chunk = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RMR_AUTOTUNE")) autotune_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("RMR_GRAPH")) graph_max_batch_ = atoi(e);
-    if (const char* e = std::getenv("RMR_GRAPH_BRANCHES")) graph_branches_ = atoi(e) != 0;
     if (const char* e = std::getenv("RMR_FUSE_LB")) fuse_lb_ = atoi(e) != 0;
     if (const char* e = std::getenv("RMR_FUSE_UP")) fuse_up_ = atoi(e) != 0;
     if (const char* e = std::getenv("RMR_SLABS")) slabs_ = atoi(e) != 0;
@@ -1284,142 +1283,6 @@ Yolov8::~Yolov8() {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
-    for (hipStream_t t : side_)
-        if (t) (void)hipStreamDestroy(t);
-}
-
-// What op `op_index` reads and writes at batch n, as whole buffers (the allocation that holds a view: channel slices of one
-// concat buffer count as the same memory, which only costs parallelism).  A fused bottleneck's first op carries the second
-// op's accesses and the second none; the leader of a run of head decodes carries the run's.
-void Yolov8::op_ranges(int op_index, int n, std::vector<Range>& rd, std::vector<Range>& wr) const {
-    const auto buf = [&](int arena, size_t off) {
-        for (const Alloc& al : allocs_)
-            if (al.arena == arena && off >= al.off && off < al.off + al.size) return Range{arena, al.off, al.off + al.size};
-        return Range{arena, 0, (size_t)-1};   // unknown: everything in that arena
-    };
-    const auto view = [&](std::vector<Range>& to, const View& v, bool f32) {
-        if (v.c || v.cs) to.push_back(buf(f32 ? 1 : 0, v.off));
-    };
-    const auto choice_of = [&](int i) {
-        const auto it = tuned_.find({i, n});
-        return it == tuned_.end() ? -1 : it->second;
-    };
-    const auto conv_access = [&](const Op& op, int choice) {
-        if (op.in_is_input)
-            rd.push_back(Range{10, 0, (size_t)-1});
-        else
-            view(rd, op.in, false);
-        view(rd, op.res, false);
-        view(rd, op.pre, true);
-        view(wr, op.out, op.out_f32);
-        if (op.fp8) rd.push_back(buf(2, op.q_off));
-        if (op.q_out) wr.push_back(buf(2, op.q_out_off));
-        if (op.in_slab_c)
-            for (int k = 1; k < op.in.c / op.in_slab_c; ++k) rd.push_back(buf(0, op.in.off + k * op.in_slab_step));
-        if (op.out_slab_c)
-            for (int k = 1; k < op.out.c / op.out_slab_c; ++k) wr.push_back(buf(0, op.out.off + k * op.out_slab_step));
-        if (choice < 0 || choice >= 1000) wr.push_back(Range{12, 0, (size_t)-1});   // split-K partial tiles and tickets
-    };
-    const Op& op = ops_[op_index];
-    switch (op.kind) {
-        case OP_CONV: {
-            const int c = choice_of(op_index);
-            if (c == kFusedAway) break;
-            conv_access(op, c);
-            if (c >= 340 && c < kFusedAway && op.fuse_with >= 0) conv_access(ops_[op.fuse_with], 0);
-            break;
-        }
-        case OP_QUANT:
-            view(rd, op.in, false);
-            wr.push_back(buf(2, op.q_off));
-            break;
-        case OP_SPPF:
-            view(rd, op.in, false);
-            view(wr, op.in, false);
-            break;
-        case OP_UP:
-            view(rd, op.in, false);
-            view(wr, op.out, false);
-            break;
-        case OP_HEAD: {
-            int b = op_index;
-            while (b > 0 && ops_[b - 1].kind == OP_HEAD) --b;
-            int lead = b, len = 0;
-            for (int i = b; i <= op_index; ++i) {
-                if (len == 3 || ops_[i].cls.cs != ops_[lead].cls.cs) lead = i, len = 0;
-                ++len;
-            }
-            if (lead != op_index) break;
-            int k = 0;
-            for (int i = op_index; i < (int)ops_.size() && k < 3 && ops_[i].kind == OP_HEAD && ops_[i].cls.cs == op.cls.cs; ++i, ++k) {
-                view(rd, ops_[i].box, true);
-                view(rd, ops_[i].cls, true);
-            }
-            wr.push_back(Range{11, 0, (size_t)-1});
-            break;
-        }
-    }
-}
-
-// Captures one forward pass of `batch` images into the capturing stream s as a DAG: every op goes to the stream that holds
-// the latest of its direct dependencies (so chains stay chains), else to the least recently used of four streams, and
-// waits for the events of its other dependencies; every stream is joined back into s at the end.
-void Yolov8::capture_dag(hipStream_t s, int batch, std::vector<hipEvent_t>& made) {
-    const int nops = (int)ops_.size();
-    std::vector<std::vector<Range>> R(nops), W(nops);
-    for (int i = 0; i < nops; ++i) op_ranges(i, batch, R[i], W[i]);
-    const auto hit = [](const std::vector<Range>& x, const std::vector<Range>& y) {
-        for (const Range& a : x)
-            for (const Range& b : y)
-                if (a.arena == b.arena && a.lo < b.hi && b.lo < a.hi) return true;
-        return false;
-    };
-    hipStream_t streams[4] = {s, nullptr, nullptr, nullptr};
-    for (int t = 0; t < 3; ++t) {
-        if (!side_[t]) RMR_HIP(hipStreamCreateWithFlags(&side_[t], hipStreamNonBlocking));
-        streams[t + 1] = side_[t];
-    }
-    std::vector<hipEvent_t> ev(nops, nullptr);
-    hipEvent_t fork = nullptr;
-    const auto new_event = [&]() {
-        hipEvent_t e;
-        RMR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        made.push_back(e);
-        return e;
-    };
-    int last_on[4] = {-1, -1, -1, -1};
-    bool joined[4] = {true, false, false, false};   // part of the capture
-    std::vector<int> stream_of(nops, 0);
-    {
-        fork = new_event();
-        RMR_HIP(hipEventRecord(fork, s));
-        for (int k = 0; k < nops; ++k) {
-            if (R[k].empty() && W[k].empty()) continue;   // launches nothing (fused away / a head decode done by its leader)
-            std::vector<int> deps;
-            for (int j = 0; j < k; ++j)
-                if (ev[j] && (hit(W[j], R[k]) || hit(R[j], W[k]) || hit(W[j], W[k]))) deps.push_back(j);
-            int t = -1;
-            for (int q = 0; q < 4; ++q)   // continue the chain of the latest direct dependency
-                if (last_on[q] >= 0 && std::find(deps.begin(), deps.end(), last_on[q]) != deps.end() && (t < 0 || last_on[q] > last_on[t])) t = q;
-            if (t < 0)
-                for (int q = 0; q < 4; ++q)   // else the least recently used stream
-                    if (t < 0 || last_on[q] < last_on[t]) t = q;
-            if (!joined[t]) {
-                RMR_HIP(hipStreamWaitEvent(streams[t], fork, 0));
-                joined[t] = true;
-            }
-            for (int d : deps)
-                if (stream_of[d] != t) RMR_HIP(hipStreamWaitEvent(streams[t], ev[d], 0));
-            run_op(streams[t], k, batch, 0);
-            ev[k] = new_event();
-            RMR_HIP(hipEventRecord(ev[k], streams[t]));
-            stream_of[k] = t;
-            last_on[t] = k;
-        }
-        for (int q = 1; q < 4; ++q)
-            if (joined[q] && last_on[q] >= 0) RMR_HIP(hipStreamWaitEvent(s, ev[last_on[q]], 0));
-            else if (joined[q]) RMR_HIP(hipStreamWaitEvent(s, fork, 0));
-    }
 }
 
 bool Yolov8::all_tuned(int n) const {
@@ -1465,23 +1328,16 @@ void Yolov8::forward(hipStream_t s, int batch) {
         if (it == graphs_.end()) {
             Graph g;
             g.src = lb_src_;
-            std::vector<hipEvent_t> events;   // the capture's fork / join events: alive until the capture has ended
             RMR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             try {
-                if (graph_branches_)
-                    capture_dag(s, batch, events);
-                else
-                    for (int i = 0; i < (int)ops_.size(); ++i) run_op(s, i, batch, 0);
+                for (int i = 0; i < (int)ops_.size(); ++i) run_op(s, i, batch, 0);
             } catch (...) {
                 hipGraph_t dead = nullptr;
                 (void)hipStreamEndCapture(s, &dead);
                 if (dead) (void)hipGraphDestroy(dead);
-                for (hipEvent_t e : events) (void)hipEventDestroy(e);
                 throw;
             }
-            const hipError_t end_err = hipStreamEndCapture(s, &g.graph);
-            for (hipEvent_t e : events) (void)hipEventDestroy(e);
-            RMR_HIP(end_err);
+            RMR_HIP(hipStreamEndCapture(s, &g.graph));
             RMR_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
             it = graphs_.emplace(batch, g).first;
         }
