@@ -343,6 +343,15 @@ class Ranks:
                 except Exception as e:  # noqa: BLE001
                     self.comm = None
                     self.gather_via += f" [C-ABI communicator unavailable: {type(e).__name__}: {e}]"
+                # every rank must take the same road from here on: one rank gathering through the C-ABI communicator while
+                # another fell back to torch.distributed would hang both
+                ok = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int32, device=self.dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and self.comm is not None:
+                    self.comm.close()
+                    self.comm = None
+                    self.gather_via = (f"torch.distributed all_gather_into_tensor ({'RCCL' if self.gpu else 'gloo'}) "
+                                       "[C-ABI communicator unavailable on another rank]")
 
     def _probe_torch(self):
         t = self.torch.full((1,), self.rank, dtype=self.torch.int32, device=self.dev)
@@ -558,8 +567,9 @@ def main(argv=None):
     stage_ms = None
     if not args.no_profile and rank == 0:
         with rmr.profile(local) as prof:
-            step()
-            sync_all()
+            # rank 0 alone: the native call without the gather (a collective here would wait for ranks that are not in this leg)
+            rmr.run_batch(rdet, loc, frames_fb, None, forced)
+            torch.cuda.synchronize()
             all_stats = prof.read(by_stage=True)
         stage_ms = {"first layer + letterbox sampling (car + armor)": 0.0, "network, car stage": 0.0, "network, armor stage": 0.0,
                     "head decode": 0.0, "box decode + NMS + restore": 0.0, "locate: update (scatter + diff)": 0.0,
