@@ -111,6 +111,11 @@ def parse(argv=None):
                     help="fp8 = BASELINE configs[4]: e4m3 weights and activations in the 3x3 layers of backbone and neck")
     ap.add_argument("--config", type=int, default=2, help="BASELINE configs index: 2 = 640x640 + 30k points; 3 = one 1920x1080 "
                     "stream + 100k-point clouds per GPU")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST HOOK (tests/test_gpu_bench_step.py): every rank computes on GPU 0, the process group is gloo and the "
+                         "robot-record exchange the C-ABI FILE transport -- the whole N > 1 control flow of main() (shards per rank, "
+                         "barriers, max-over-ranks clock, rank-0-only legs) on a one-GPU box; everything except RCCL itself.  The "
+                         "line says \"share_gpu\": true: ranks that share a chip do not measure scaling")
     ap.add_argument("--stub-step", action="store_true",
                     help="TEST HOOK (tests/test_bench_launcher.py): the launcher, process group (gloo), C-ABI communicator (FILE "
                          "transport), barriers, max-over-ranks clock and JSON assembly run for real on CPU; the GPU step is replaced "
@@ -135,7 +140,7 @@ def launch_ranks(args, argv):
     torch.distributed.run -- the command form the contract gives for N > 1 -- and hand back its exit code.  A box
     with fewer than N GPUs is an error, never a silent one-rank run."""
     import subprocess
-    if not args.stub_step:
+    if not args.stub_step and not args.share_gpu:
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -305,7 +310,7 @@ class Ranks:
     C-ABI communicator of the robot-record exchange (include/rmr.h rmr_comm_*: RCCL on GPUs, the FILE transport
     on CPU), the barrier and the max-over-ranks clock of the contract."""
 
-    def __init__(self, args, backend, transport, device=None):
+    def __init__(self, args, backend, transport, device=None, compute_on_gpu=None):
         import torch
         import torch.distributed as dist
         from rm_radar_amd import dist as rd
@@ -313,19 +318,22 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        self.gpu = backend == "nccl"
+        self.nccl = backend == "nccl"                 # collectives on device tensors over RCCL (else gloo on host tensors)
+        self.gpu = self.nccl if compute_on_gpu is None else compute_on_gpu   # the step runs on a GPU: synchronise it around the clock
+        if getattr(args, "share_gpu", False):
+            self.local = 0
         # under torch.distributed.run (RANK set) the process group is always created, also for one
         # rank, so the RCCL path is exercised by every launcher-driven run
         self.use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            kw = {"device_id": torch.device("cuda", self.local)} if self.gpu else {}
+            kw = {"device_id": torch.device("cuda", self.local)} if self.nccl else {}
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
-        self.dev = torch.device("cuda", self.local) if self.gpu else torch.device("cpu")
+        self.dev = torch.device("cuda", self.local) if self.nccl else torch.device("cpu")
         self.comm, self.ranks_seen = None, [0]
         self.gather_via = "none (one rank, no process group)"
         if self.use_dist:
-            self.gather_via = f"torch.distributed all_gather_into_tensor ({'RCCL' if self.gpu else 'gloo'})"
+            self.gather_via = f"torch.distributed all_gather_into_tensor ({'RCCL' if self.nccl else 'gloo'})"
             self.ranks_seen = self._probe_torch()
             if args.gather == "abi":
                 # the 128-byte id travels over the torch.distributed group that exists anyway for the barrier and
@@ -350,7 +358,7 @@ class Ranks:
                 if int(ok.item()) == 0 and self.comm is not None:
                     self.comm.close()
                     self.comm = None
-                    self.gather_via = (f"torch.distributed all_gather_into_tensor ({'RCCL' if self.gpu else 'gloo'}) "
+                    self.gather_via = (f"torch.distributed all_gather_into_tensor ({'RCCL' if self.nccl else 'gloo'}) "
                                        "[C-ABI communicator unavailable on another rank]")
 
     def _probe_torch(self):
@@ -455,8 +463,9 @@ def main(argv=None):
     from rm_radar_amd import dist as rd
     from rm_radar_amd import weights as W
 
-    R = Ranks(args, "nccl", "rccl")
-    world, rank, local, use_dist, dev = R.world, R.rank, R.local, R.use_dist, R.dev
+    R = Ranks(args, "gloo", "file", compute_on_gpu=True) if args.share_gpu else Ranks(args, "nccl", "rccl")
+    world, rank, local, use_dist = R.world, R.rank, R.local, R.use_dist
+    dev = torch.device("cuda", local)   # where the step's inputs live (R.dev is where the collectives' tensors live)
     torch.cuda.set_device(local)
 
     pack_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rmr_packs")
@@ -712,6 +721,7 @@ def main(argv=None):
             "value": frames / dt,
             "unit": "frames/s",
             "n_gpus": world,
+            **({"share_gpu": True} if args.share_gpu else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,

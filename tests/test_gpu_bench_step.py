@@ -124,3 +124,25 @@ def test_config3_step_matches_oracle(bench, oracle, packs):
         assert s["robots"] >= 8
         assert s["max_xyz_err_m"] <= 1e-3
     assert stats[0]["located"] >= 6 and stats[1]["located"] >= 8   # frames 0-1 of step one are background-only clouds
+
+
+def test_two_ranks_through_the_whole_bench_flow_on_one_gpu():
+    """`bench.py --gpus 2 --share-gpu`: the N > 1 control flow of the bench's main() for real -- the launcher starts two ranks
+    under torch.distributed.run, each owns its own streams' frames, detectors and Locator, the timed region is bracketed by
+    barriers, the clock is the slower rank's, the robot records travel through the C-ABI communicator (FILE transport here,
+    RCCL on a real multi-GPU node), and the legs only rank 0 runs (stage breakdown, upload ring) must not call a collective.
+    Both ranks compute on GPU 0, so the line carries "share_gpu": true and its rate says nothing about scaling."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-latency", "--no-parity", "--seconds", "0", "--profile-steps", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["share_gpu"] is True and line["ranks_seen"] == [0, 1]
+    assert len(line["per_rank_frames_per_s"]) == 2 and line["value"] > 0
+    assert "FILE transport" in line["gather"], line["gather"]
+    assert line["stage_ms_per_step"]["network, armor stage"] > 0        # rank 0's own leg ran to the end
+    assert line["value"] <= sum(line["per_rank_frames_per_s"]) * 1.001    # whole-job rate from the slower rank's clock
