@@ -835,12 +835,9 @@ __global__ __launch_bounds__(512) void conv_wsf_kernel(const ConvArgs a, const i
     const auto out_off = [&](int c) { return cp(c) * out_pitch2 + out_co2 + cqq(c) * 16u; };
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, OUT32 ? 0u : 0xfffffff0u, 0x00020000);
 
-    // fragment reads run PF K steps ahead of their MFMAs: a K step is only three MFMAs (51 cycles) here, and with two K
-    // steps of distance the wave waited for LDS at every step (measured: 9 500 cycles per row against 3 360 of MFMA work)
-#ifndef RMR_WSF_PF
-#define RMR_WSF_PF 4
-#endif
-    constexpr int PF = RMR_WSF_PF, XR = PF + 1;
+    // fragment reads run PF K steps ahead of their MFMAs.  (A K step is only three MFMAs here; distances of 2, 3 and 4 K steps
+    // measured the same 790-800 us per launch at 256 images -- the wave does not wait for LDS -- and 6 spills: PF = 2.)
+    constexpr int PF = 2, XR = PF + 1;
     floatx4 acc[3];
     half8 xf[XR];
     unsigned A0 = 0, A1 = 0, A2 = 0;   // this lane's fragment address in the three ring rows a step reads
@@ -966,9 +963,7 @@ __global__ __launch_bounds__(512) void conv_wsf_kernel(const ConvArgs a, const i
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden-row writes (and ring reads) of the step before
         __builtin_amdgcn_s_barrier();
         issue_row(s + 4);   // into the slot of row s - 2, the shortcut row of step s - 1
-#ifdef RMR_WSF_STAGGER
-        if (role == 1) __builtin_amdgcn_s_sleep(RMR_WSF_STAGGER);   // experiment: the two waves of a SIMD half a tile out of phase
-#endif
+        // (starting the conv2 waves 256-768 cycles late, so that the two waves of a SIMD are half a tile out of phase: no change)
         // (opaque copies: the optimiser otherwise keeps "lane offset + slot base" for every slot and tile as induction variables
         // across the step loop -- twenty-odd registers this kernel does not have)
         unsigned lane_off_s = lane_off, mf_off_s = mf_off;
