@@ -19,9 +19,12 @@ for i in range(10):
     im.save(path, quality=90)
     total += os.path.getsize(path)
 print("wrote", OUT, total, "bytes")
-# ... and ONE frame at its own size (2592 x 2048, re-encoded at quality 80: ~0.5 MB), so that configs[1] also runs once on a
-# reference frame at the reference's resolution and calibration (the letterbox of a 2592 x 2048 frame has the Q2 row quirk)
-im = Image.open(f"{REF}/0.jpg").convert("RGB")
-path = os.path.join(OUT, "full_0.jpg")
-im.save(path, quality=80)
-print("wrote", path, os.path.getsize(path), "bytes")
+# ... and frames at their own size (2592 x 2048, re-encoded at quality 80: ~0.5 MB each), so that configs[1] also runs on
+# reference frames at the reference's resolution and calibration (the letterbox of a 2592 x 2048 frame has the Q2 row quirk)
+# (round 4: three frames -- 0, 4 and 9 -- so that the full-size case is a SEQUENCE: the Locator's background and depth ring
+# carry over from frame to frame, as in the sample application)
+for i in (0, 4, 9):
+    im = Image.open(f"{REF}/{i}.jpg").convert("RGB")
+    path = os.path.join(OUT, f"full_{i}.jpg")
+    im.save(path, quality=80)
+    print("wrote", path, os.path.getsize(path), "bytes")

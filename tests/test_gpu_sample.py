@@ -48,6 +48,17 @@ def test_sample_radar_on_a_reference_frame_at_its_own_size(tmp_path_factory, ora
     _run_once_case(tmp_path_factory, oracle, [frame], scenes.SAMPLE_SIZE, scenes.SAMPLE_K)
 
 
+def test_sample_radar_on_a_sequence_of_reference_frames_at_their_own_size(tmp_path_factory, oracle):
+    """The same at full size as a SEQUENCE (round 4: frames 0, 4 and 9 of the reference's sample, each with its own sample
+    cloud): the Locator's background and depth ring carry over from frame to frame as in samples/main.cpp:85-99."""
+    from rm_radar_amd import assets
+    gold = os.path.join(os.path.dirname(__file__), "golden", "assets_images")
+    ids = (0, 4, 9)
+    frames = [assets.read_image(os.path.join(gold, f"full_{i}.jpg")) for i in ids]
+    assert all(f.shape == (2048, 2592, 3) for f in frames)
+    _run_once_case(tmp_path_factory, oracle, frames, scenes.SAMPLE_SIZE, scenes.SAMPLE_K, cloud_ids=ids)
+
+
 def _oracle_two_stage(oracle, img, car_head, p, armor_ref, cache, car_conf, armor_conf):
     """RobotDetector::detect (detector.cpp:413-455) from the oracles, armor heads cached per crop rect.  Returns
     (cars, grouped robots, smallest margin of a label vote: robot.cpp's score_map sums confidences per label)."""
@@ -70,6 +81,7 @@ def _oracle_two_stage(oracle, img, car_head, p, armor_ref, cache, car_conf, armo
         if len(v) > 1:
             vote_margin = min(vote_margin, v[0] - v[1])
         robots.append(oracle.make_robot(tuple(c), armors))
+    _oracle_two_stage.ungrouped = robots   # the robots before the per-label grouping (for the near-tie rule of _run_once_case)
     return cars, oracle.group_robots(robots, 0.75), vote_margin
 
 
@@ -104,7 +116,7 @@ def _robust_thresholds(oracle, frames, heads, armor_ref, caches, margin=0.02):
     return best[1], best[2], best[3]
 
 
-def _run_once_case(tmp_path_factory, oracle, frames, size, K_cam, min_box=40):
+def _run_once_case(tmp_path_factory, oracle, frames, size, K_cam, min_box=40, cloud_ids=None):
     import rm_radar_amd as rmr
     from oracle import yolov8_ref as R
     from rm_radar_amd.sample import SampleRadar
@@ -136,12 +148,13 @@ def _run_once_case(tmp_path_factory, oracle, frames, size, K_cam, min_box=40):
         # first find where the oracle's cars are, then drop LiDAR returns 2 m in front of the
         # background inside those boxes, on top of the reference's sample cloud
         cars, want, _ = _oracle_two_stage(oracle, img, heads[f][0], heads[f][1], armor_ref, caches[f], car_conf, armor_conf)
+        ungrouped = list(_oracle_two_stage.ungrouped)
         robots_spec = [((float(c["x"]), float(c["y"]), float(c["width"]), float(c["height"])), 2000.0, 300)
                        for c in cars if c["width"] > min_box and c["height"] > min_box][:4]
         extra = scenes.make_cloud(rng, 20000, K_cam, scenes.SAMPLE_L2C, size, robots_spec,
                                   zero_frac=0, far_frac=0)
         asset = np.zeros((10000, 4), np.float32)
-        asset[:, :3] = data[f"cloud{f}"]
+        asset[:, :3] = data[f"cloud{cloud_ids[f] if cloud_ids else f}"]
         cloud = np.concatenate([asset, extra])
         got = radar.run_once(img, cloud)
 
@@ -169,10 +182,24 @@ def _run_once_case(tmp_path_factory, oracle, frames, size, K_cam, min_box=40):
         for w in want:
             wl = w.label if w.has_label else None
             partner = [g for g in got if g.label == wl and netutil.iou_xywh(g.rect, tuple(w.rect)) >= 0.99]
-            assert partner, f"no partner for robot label {wl} rect {tuple(w.rect)}"
+            twin_rule = False
+            if not partner and wl is not None:
+                # the grouping keeps ONE robot per label, the most confident (detector.cpp:427-454).  Two robots of one label
+                # whose confidences are closer than the f16 score error (observed: 0.904 against 0.907) are a coin toss:
+                # the GPU may keep the other one -- which must then be that other robot of the oracle, before grouping
+                for g in got:
+                    if g.label != wl:
+                        continue
+                    twin = [r for r in ungrouped if r.has_label and int(r.label) == wl and
+                            netutil.iou_xywh(g.rect, tuple(r.rect)) >= 0.99 and abs(float(r.confidence) - float(w.confidence)) <= 0.02]
+                    if twin:
+                        partner, twin_rule = [g], True
+            assert partner, (f"frame {f}: no partner for robot label {wl} rect {tuple(w.rect)}; GPU robots "
+                             f"{[(g.label, tuple(round(v, 1) for v in g.rect), None if g.confidence is None else round(g.confidence, 3)) for g in got]}; "
+                             f"oracle {[(x.label if x.has_label else None, tuple(round(v, 1) for v in x.rect), round(x.confidence, 3)) for x in want]}")
             loc = cpu_loc.search(tuple(w.rect))
             loc_g = cpu_loc.search(partner[0].rect)
-            if loc is not None and loc_g is not None:
+            if loc is not None and loc_g is not None and not twin_rule:   # (a twin is another robot: its own location was checked above)
                 assert np.max(np.abs(loc - loc_g)) <= 0.05  # same robot, sub-pixel rect change
     assert total_located >= 1
 
