@@ -180,6 +180,11 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
                       const float* bias, int cout, int kh, int kw, int stride, int pad, int silu,
                       const float* residual, float* y, int tile);
 
+/* Version of the tuning-cache / kernel-plan file format this library reads and writes ('<pack>.tune', RMR_PLAN): the second
+ * field of the file's header line.  It moves whenever the set of candidate kernels does, so a plan file of another version is
+ * ignored (an engine cache of another TensorRT version, detector.cpp:74-99).  No GPU needed. */
+int rmr_tune_file_version(void);
+
 /* Host side of the fp8 weight packer: OCP e4m3fn bytes of x[n], round to nearest even, saturating at 448
  * (conv_t32f8.hip; the counterpart of choosing kFP16 / kINT8 at detector.cpp:208-231). */
 rmr_status rmr_f32_to_e4m3(const float* x, int n, unsigned char* out);

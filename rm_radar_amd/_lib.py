@@ -159,6 +159,7 @@ SYMBOLS = {
     "rmr_robot_detector_detect": (C.c_int, [_vp, _P(Image), _P(Robot), _ip, C.c_int]),
     "rmr_robot_detector_detect_batch": (C.c_int, [_vp, _P(Image), C.c_int, _ip, C.c_int,
                                                   _P(Robot), _ip, C.c_int]),
+    "rmr_tune_file_version": (C.c_int, []),
     "rmr_pinned_alloc": (C.c_int, [C.c_size_t, _P(_vp)]),
     "rmr_pinned_alloc_on": (C.c_int, [C.c_int, C.c_size_t, _P(_vp)]),
     "rmr_pinned_free": (None, [_vp]),

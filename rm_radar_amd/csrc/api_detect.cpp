@@ -360,6 +360,8 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
     });
 }
 
+int rmr_tune_file_version(void) { return rmr::Yolov8::tune_file_version(); }
+
 // Host e4m3 rounding of the weight packer (round to nearest even, OCP e4m3fn), for the CPU tests.
 rmr_status rmr_f32_to_e4m3(const float* x, int n, unsigned char* out) {
     return guarded([&] {

@@ -36,6 +36,7 @@ struct View {
 
 class Yolov8 {
    public:
+    static int tune_file_version();   // the header version of '<pack>.tune' / RMR_PLAN files this build reads and writes
     // in_w/in_h: network input size (multiples of 32); max_batch: largest forward() batch
     // fp8: the 3x3 / stride-1 layers with >= 64 input channels run on e4m3 operands (RMR_FP8=1 forces it)
     Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int in_w, int in_h,
