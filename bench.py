@@ -93,7 +93,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1, help="cpu_baseline: timed frames per worker")
-    ap.add_argument("--cpu-workers", type=int, default=0, help="cpu_baseline: frames in flight (0 = cores / 8)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="cpu_baseline: frames in flight (0 = cores / 4)")
     ap.add_argument("--launch-order", default="", help="write the enqueue order of the profiled launches (layer, FLOPs, bytes) to this "
                     "file (RMR_PROFILE_ORDER): what tools/pmc_traffic.py maps the dispatches of a rocprofv3 --pmc pass with")
     ap.add_argument("--no-parity", action="store_true", help="skip the step-parity leg (parity_checked: false)")
@@ -224,8 +224,8 @@ def cpu_baseline(args, packs, images, clouds, rects):
     """The same frames on the host CPU: C oracle (pre / decode+NMS / locate) + PyTorch-CPU fp32 YOLOv8m (oneDNN) standing in
     for ONNX-Runtime-CPU + PCL, which this image lacks.  SURVEY 8d: frames in parallel -- W workers (threads: torch's CPU
     ops and the ctypes oracle both release the GIL), each with its own Locator stream and its own share of the frames,
-    torch intra-op threads = cores / W per worker; cores = what this process may run on (sched_getaffinity).  W = cores / 8
-    by default, one frame per worker: about 30 s on the GPU box's 256 cores."""
+    torch intra-op threads = cores / W per worker; cores = what this process may run on (sched_getaffinity).  W = cores / 4
+    by default (at most one worker per frame of the batch), one frame per worker: about 40 s on the GPU box's 256 cores."""
     from concurrent.futures import ThreadPoolExecutor
 
     import torch
@@ -234,7 +234,9 @@ def cpu_baseline(args, packs, images, clouds, rects):
     import scenes
     from oracle import yolov8_ref as R
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    workers = max(1, min(args.cpu_workers or max(1, cores // 8), cores, args.batch))
+    # measured on the GPU box's 256 cores (frames/s at one frame per worker): 16 x 16 threads 0.61, 32 x 8 0.86, 64 x 4 1.59 --
+    # the more frames in flight the better oneDNN's batch-1 / batch-4 convolutions use the cores: cores / 4 workers
+    workers = max(1, min(args.cpu_workers or max(1, cores // 4), cores, args.batch))
     threads = max(1, cores // workers)
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(threads)
