@@ -1,6 +1,8 @@
 // api_detect.cpp -- C-ABI entry points (include/rmr.h) for Detector, RobotDetector and the
 // single-layer conv hook.
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -513,6 +515,13 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
             a.splitk_ws = sk_ws.p;
             a.splitk_cnt = sk_cnt.p;
         }
+#ifdef RMR_T32_FINISH
+        if (tile >= 800 && tile < 900) {   // development build: two 64-bit stamps per workgroup (conv_t32.hip)
+            sk_ws.alloc(4 * 2 * ctx.num_cus * 4);
+            RMR_HIP(hipMemsetAsync(sk_ws.p, 0, sk_ws.n * sizeof(float), ctx.stream));
+            a.splitk_ws = sk_ws.p;
+        }
+#endif
         const auto launch = [&] {
             if (tile >= 1000 && tile % 1000 >= 800 && tile % 1000 < 900) {
                 launch_conv_t32(ctx, ctx.stream, a, tile % 1000 - 800);
@@ -582,6 +591,28 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         *ms_out = ms / reps;
+#ifdef RMR_T32_FINISH
+        if (tile >= 800 && tile < 900) {   // the last launch's stamps: start / finish of every workgroup, in us from the first start
+            std::vector<unsigned long long> st(sk_ws.n / 2);
+            RMR_HIP(hipMemcpy(st.data(), sk_ws.p, st.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> b, e;
+            unsigned long long t0 = ~0ull;
+            for (size_t i = 0; i + 1 < st.size(); i += 2)
+                if (st[i + 1]) t0 = std::min(t0, st[i]);
+            for (size_t i = 0; i + 1 < st.size(); i += 2)
+                if (st[i + 1]) b.push_back((st[i] - t0) * 0.01), e.push_back((st[i + 1] - t0) * 0.01);
+            if (!e.empty()) {
+                std::sort(e.begin(), e.end());
+                std::sort(b.begin(), b.end());
+                double mean = 0;
+                for (double v : e) mean += v;
+                mean /= e.size();
+                const auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+                std::fprintf(stderr, "[t32 finish] %zu workgroups: start p50 %.1f max %.1f us | finish min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f mean %.1f us (launch %.1f us)\n",
+                             e.size(), q(b, 0.5), b.back(), e.front(), q(e, 0.1), q(e, 0.5), q(e, 0.9), e.back(), mean, ms / reps * 1e3);
+            }
+        }
+#endif
     });
 }
 

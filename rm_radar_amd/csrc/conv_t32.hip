@@ -116,6 +116,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     };
     int vb = 0;
     if (!tile_valid(0)) return;
+#ifdef RMR_T32_FINISH
+    // development build: when every workgroup started and finished (100 MHz clock), for the spread of the static walk
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     int m0, n0;
     tile_m0n0(vb, m0, n0);
     const int my_tile = tile_id, my_z = zsplit;
@@ -485,6 +489,13 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
         n0 = n0n;
     }
     wait_vm<0>();
+#ifdef RMR_T32_FINISH
+    if (split == 1 && a.splitk_ws && threadIdx.x == 0) {
+        unsigned long long* const rec = (unsigned long long*)a.splitk_ws + 2 * blockIdx.x;
+        rec[0] = t_begin;
+        rec[1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 
