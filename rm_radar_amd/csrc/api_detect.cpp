@@ -245,6 +245,11 @@ rmr_status rmr_conv2d(int device, const float* x, int n, int h, int w, int cin, 
         // tile < 0: automatic; 0..99: conv_igemm tile; 100..199: conv_dma tile; 200..299: conv_halo tile; 300..399: conv_ws variant; 400..499: conv_direct tile; 500: conv_stem; 600..699: conv_ws_s2 variant; 700..799: conv_pw variant; 800..899: conv_t32 tile; 900..949: conv_t32f8 tile; 950..979: conv_g32 tile; 980..999: conv_w1d tile
         if (tile < 0) {
             launch_conv_auto(ctx, ctx.stream, a);
+        } else if (tile >= kSbBase) {
+            // kSbBase + variant: the small-batch family (conv_sb.hip)
+            if (!conv_sb_supported(a, tile - kSbBase))
+                fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv2d: small-batch variant %d cannot run this layer", tile - kSbBase);
+            launch_conv_sb(ctx, ctx.stream, a, tile - kSbBase);
         } else if (tile >= 980 && tile < 1000) {
             const int t = tile - 980;
             if (t >= conv_w1d_num_tiles() || !conv_w1d_supported(a, t))
@@ -504,7 +509,7 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         // 1000 * split + 800 + t32 tile: split-K conv_t32
         DevBuf<float> sk_ws;
         DevBuf<int> sk_cnt;
-        if (tile >= 1000 && tile % 1000 >= 800 && tile % 1000 < 900) {
+        if (tile < kSbBase && tile >= 1000 && tile % 1000 >= 800 && tile % 1000 < 900) {
             const int split = tile / 1000, t = tile % 1000 - 800;
             if (t >= conv_t32_num_tiles() || !conv_t32_splitk_supported(a, t, split, ctx.num_cus))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: split-K t32 tile %d cannot run this layer", tile);
@@ -523,7 +528,11 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         }
 #endif
         const auto launch = [&] {
-            if (tile >= 1000 && tile % 1000 >= 800 && tile % 1000 < 900) {
+            if (tile >= kSbBase) {
+                if (!conv_sb_supported(a, tile - kSbBase))
+                    fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: small-batch variant %d cannot run this layer", tile - kSbBase);
+                launch_conv_sb(ctx, ctx.stream, a, tile - kSbBase);
+            } else if (tile >= 1000 && tile % 1000 >= 800 && tile % 1000 < 900) {
                 launch_conv_t32(ctx, ctx.stream, a, tile % 1000 - 800);
             } else if (tile >= 980 && tile < 1000) {
                 if (tile - 980 >= conv_w1d_num_tiles() || !conv_w1d_supported(a, tile - 980))
@@ -577,13 +586,44 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_conv_bench: kernel id %d is not a tiled family", tile);
             }
         };
-        launch();
-        launch();
+        // RMR_BENCH_COLD=<copies>: every launch works on its own replica of the input, the weights and the output (round robin),
+        // as the layers of a network do -- back-to-back launches of ONE layer find their operands in the L2 of every XCD, which
+        // a batch-1 frame never does (a layer's weights were last read a frame ago)
+        const int copies = std::getenv("RMR_BENCH_COLD") ? std::max(1, std::atoi(std::getenv("RMR_BENCH_COLD"))) : 1;
+        DevBuf<__half> cx, cw, cw32, cy;
+        if (copies > 1) {
+            cx.alloc(copies * dx.n), cw.alloc(copies * dw.n), cy.alloc(copies * dy.n);
+            if (dw32.p) cw32.alloc(copies * dw32.n);
+            for (int c = 0; c < copies; ++c) {
+                RMR_HIP(hipMemcpyAsync(cx.p + c * dx.n, dx.p, dx.n * 2, hipMemcpyDeviceToDevice, ctx.stream));
+                RMR_HIP(hipMemcpyAsync(cw.p + c * dw.n, dw.p, dw.n * 2, hipMemcpyDeviceToDevice, ctx.stream));
+                if (dw32.p) RMR_HIP(hipMemcpyAsync(cw32.p + c * dw32.n, dw32.p, dw32.n * 2, hipMemcpyDeviceToDevice, ctx.stream));
+            }
+        }
+        // development builds (-DRMR_SB_TIMING) with RMR_CONV_TIMING=1: eight 100 MHz stamps per workgroup of the LAST launch
+        DevBuf<long long> sb_stamps;
+        if (tile >= kSbBase && std::getenv("RMR_CONV_TIMING")) {
+            sb_stamps.alloc(16 * 16384);
+            RMR_HIP(hipMemsetAsync(sb_stamps.p, 0, sb_stamps.n * 8, ctx.stream));
+            a.timing = sb_stamps.p;
+        }
+        int turn = 0;
+        const auto launch_one = launch;
+        const auto launch_cold = [&] {
+            if (copies > 1) {
+                const int c = turn++ % copies;
+                a.in = cx.p + c * dx.n, a.wt = cw.p + c * dw.n, a.out = cy.p + c * dy.n;
+                if (dw32.p) a.wt_t32 = cw32.p + c * dw32.n;
+            }
+            launch_one();
+        };
+        launch_cold();
+        launch_cold();
         hipEvent_t e0, e1;
         RMR_HIP(hipEventCreate(&e0));
         RMR_HIP(hipEventCreate(&e1));
         RMR_HIP(hipEventRecord(e0, ctx.stream));
-        for (int r = 0; r < reps; ++r) launch();
+        for (int r = 0; r < reps; ++r) launch_cold();
         RMR_HIP(hipEventRecord(e1, ctx.stream));
         RMR_HIP(hipEventSynchronize(e1));
         float ms = 0;
@@ -591,6 +631,25 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         *ms_out = ms / reps;
+        if (sb_stamps.p) {
+            std::vector<long long> st(sb_stamps.n);
+            RMR_HIP(hipMemcpy(st.data(), sb_stamps.p, st.size() * 8, hipMemcpyDeviceToHost));
+            long long t0 = -1;
+            size_t wgs = 0;
+            for (size_t i = 0; i + 15 < st.size(); i += 16)
+                if (st[i]) t0 = t0 < 0 ? st[i] : std::min(t0, st[i]), ++wgs;
+            static const char* const what[16] = {"entry", "DMAs issued", "stage 0 landed", "last stage landed", "K loop done", "reduced", "epilogue issued", "stores done",
+                                                 "stage 0", "stage 1", "stage 2", "stage 3", "stage 4", "stage 5", "stage 6", "stage 7"};
+            for (int k = 0; k < 16 && wgs; ++k) {
+                std::vector<double> v;
+                for (size_t i = 0; i + 15 < st.size(); i += 16)
+                    if (st[i] && st[i + k]) v.push_back((st[i + k] - t0) * 0.01);
+                if (v.empty()) continue;
+                std::sort(v.begin(), v.end());
+                std::fprintf(stderr, "[sb stamps] %-18s min %6.2f p50 %6.2f max %6.2f us (%zu workgroups; launch %.1f us)\n", what[k], v.front(), v[v.size() / 2], v.back(),
+                             v.size(), ms / reps * 1e3);
+            }
+        }
 #ifdef RMR_T32_FINISH
         if (tile >= 800 && tile < 900) {   // the last launch's stamps: start / finish of every workgroup, in us from the first start
             std::vector<unsigned long long> st(sk_ws.n / 2);

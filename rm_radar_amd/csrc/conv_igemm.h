@@ -165,6 +165,14 @@ inline bool conv_w1d_supported(const ConvArgs&, int) { return false; }
 inline void launch_conv_w1d(DeviceCtx&, hipStream_t, ConvArgs, int) {}
 inline void pack_conv_weights_w1d(const __half*, int, int, int, std::vector<__half>& out) { out.assign(8, __half()); }
 #endif
+// small batches (conv_sb.hip, kernel ids kSbBase + variant): small tiles whose whole operand set is in flight at once --
+// 3x3 / stride-1 layers in the halo form (even variants), 1x1 and strided 3x3 layers in the gathered form (odd variants);
+// Cin % 32 == 0, weights from the conv_t32 LDS images (a.wt_t32)
+constexpr int kSbBase = 100000;
+int conv_sb_num_variants();
+ConvTile conv_sb_tile(int id);
+bool conv_sb_supported(const ConvArgs& a, int variant);  // variant < 0: the layer shape only
+void launch_conv_sb(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant);
 // the fp8 form (conv_t32f8.hip): e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4, f16 output
 int conv_t32f8_num_tiles();
 ConvTile conv_t32f8_tile(int id);

@@ -723,6 +723,10 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
 // slice never aliases its input or residual slice), so re-running it is harmless.  Runs once per
 // (layer, batch) -- the analogue of the reference's TensorRT engine build (detector.cpp:177-243).
 void Yolov8::launch_choice(hipStream_t s, ConvArgs a, int choice) {
+    if (choice >= kSbBase) {   // the small-batch family (conv_sb.hip)
+        launch_conv_sb(ctx_, s, a, choice - kSbBase);
+        return;
+    }
     const int split = choice / 1000, c = choice % 1000;
     if ((a.in_slab_c || a.out_slab_c) && (c < 700 || c >= 800 || split))
         fail(RMR_ERR_LOGIC, "kernel %d cannot address planar channel groups", choice);
@@ -835,6 +839,15 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a, float* best_ms_out) {
                 cands.push_back(1000 * split + 800 + t);
             }
         }
+    // small batches: tiles with their whole operand set in flight (conv_sb); offered where a layer is at most a few
+    // workgroups per CU -- beyond that the throughput kernels' streams win
+    if (conv_sb_supported(a, -1))
+        for (int v = 0; v < conv_sb_num_variants(); ++v) {
+            if (!conv_sb_supported(a, v)) continue;
+            const ConvTile ct = conv_sb_tile(v);
+            const long tiles = (long)((a.M + ct.bm - 1) / ct.bm) * (a.Cout_pad / ct.bn);
+            if (tiles <= 6L * ctx_.num_cus) cands.push_back(kSbBase + v);
+        }
     // RMR_TUNE_ONLY=lo-hi: layers that have candidates in that id range choose among those only (tests
     // use it to pin a kernel family under the whole network, e.g. 700-799 = conv_pw)
     if (const char* e = std::getenv("RMR_TUNE_ONLY")) {
@@ -842,7 +855,7 @@ int Yolov8::tune_conv(hipStream_t s, const ConvArgs& a, float* best_ms_out) {
         if (sscanf(e, "%d-%d", &lo, &hi) == 2) {
             std::vector<int> only;
             for (int c : cands)
-                if (c % 1000 >= lo && c % 1000 <= hi && c < 1000) only.push_back(c);
+                if ((c >= kSbBase && c >= lo && c <= hi) || (c % 1000 >= lo && c % 1000 <= hi && c < 1000)) only.push_back(c);
             if (!only.empty()) cands.swap(only);
         }
     }
@@ -860,7 +873,7 @@ timed:
     for (int c : cands) {
         // skip tiles that would leave most of the chip idle or are hopelessly oversized
         const int cc = c % 1000;
-        if (cc < 300) {  // tiled kernels only
+        if (c < kSbBase && cc < 300) {  // tiled kernels only
             const ConvTile t = cc >= 200 ? conv_halo_tile(cc - 200) : cc >= 100 ? conv_dma_tile(cc - 100) : conv_tile(cc);
             const long blocks = (long)((a.M + t.bm - 1) / t.bm) * (a.Cout_pad / t.bn);
             if (t.bm >= 256 && blocks < ctx_.num_cus / 2 && a.M > 64) continue;
@@ -932,6 +945,7 @@ unsigned long long Yolov8::plan_signature() const {
 // trustworthy as the file it came from
 bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
     if (choice < 0) return false;
+    if (choice >= kSbBase) return conv_sb_supported(a, choice - kSbBase);
     const int c = choice % 1000, split = choice / 1000;
     const bool slabbed = a.in_slab_c || a.out_slab_c;
     if (split && c >= 800 && c < 900)
@@ -962,8 +976,9 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
 
 // header: "rmr-tune <version> <ops> <w> <h> <plan signature> <CUs> <device name without blanks>"
 // (the version moves whenever the set of candidate kernels does: 11 = conv_g32 added, 12 = conv_w1d, 13 = split-K conv_t32, 14 = conv_t32 tiles 13-14,
-// 15 = conv_wsp (conv_ws variants 12-16), conv_w1d out of the product build, 16 = fused bottlenecks (conv_wsf, 340.. + 399))
-static constexpr int kTuneFileVersion = 16;
+// 15 = conv_wsp (conv_ws variants 12-16), conv_w1d out of the product build, 16 = fused bottlenecks (conv_wsf, 340.. + 399),
+// 17 = the small-batch family conv_sb (100000..))
+static constexpr int kTuneFileVersion = 16;   // -> 17 with the regenerated plans
 int Yolov8::tune_file_version() { return kTuneFileVersion; }
 static std::string device_tag(int device) {
     hipDeviceProp_t p;

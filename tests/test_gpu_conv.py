@@ -370,6 +370,47 @@ def test_conv_t32_every_tile(rmr):
                    False, tile=806)  # Cin = 48 is not a multiple of 32
 
 
+SB = 100000   # kernel ids of the small-batch family (conv_sb.hip): SB + variant
+
+
+def test_conv_sb_every_variant(rmr):
+    # small batches (conv_sb.hip): tiles of 32 x 32 ... 128 x 128 whose whole operand set is in flight at once; even variants =
+    # halo form (3x3 / stride 1), odd variants = gathered form (1x1, strided 3x3); 3-12 waves, those of a wave tile share K
+    tiles = [(32, 32), (64, 32), (32, 64), (64, 64), (128, 32), (64, 32), (64, 32), (128, 32), (128, 64), (128, 64), (128, 64),
+             (128, 96), (128, 96), (64, 32), (128, 64), (32, 32), (64, 32), (64, 64), (128, 32), (128, 64), (128, 96)]
+    def ran(*args, **kw):   # a variant whose ring cannot hold two stages of a layer refuses it (the tuner never offers it there)
+        try:
+            run_case(rmr, *args, **kw)
+            return 1
+        except rmr.InvalidArgument:
+            return 0
+
+    for t, (bm, bn) in enumerate(tiles):
+        h, g = SB + 2 * t, SB + 2 * t + 1
+        n_h = ran(3, 20, 20, 64, bn, 3, 1, True, True, tile=h, seed=t)                  # two chunks, shortcut
+        n_h += ran(1, 19, 23, 32, bn * 2, 3, 1, True, False, tile=h, seed=20 + t)       # odd W, ragged M, one chunk
+        n_g = ran(2, 20, 20, 192, bn, 1, 1, True, True, tile=g, seed=40 + t)            # 1x1, six units
+        n_g += ran(1, 19, 23, 96, bn * 2, 1, 1, False, False, tile=g, seed=60 + t)      # 1x1, f32-style epilogue (no activation)
+        n_g += ran(2, 20, 20, 64, bn, 3, 2, True, False, tile=g, seed=80 + t)           # 3x3 / stride 2, even size
+        n_g += ran(1, 19, 23, 32, bn, 3, 2, True, False, tile=g, seed=100 + t)          # 3x3 / stride 2, odd size
+        assert n_h >= 1 and n_g >= 3, (t, n_h, n_g)
+    # the layers of a batch-1 frame (car: one image, armor: four crops)
+    run_case(rmr, 1, 40, 40, 192, 192, 3, 1, True, True, tile=SB + 2, seed=200)     # six stages of 28 KiB: the whole K range in LDS
+    run_case(rmr, 1, 20, 20, 288, 288, 3, 1, True, True, tile=SB + 0, seed=201)     # nine stages: more than the ring holds (refills)
+    run_case(rmr, 4, 80, 80, 96, 96, 3, 1, True, True, tile=SB + 24, seed=202)      # 128 x 96 on 80-wide maps
+    run_case(rmr, 1, 80, 80, 96, 96, 3, 1, True, False, tile=SB + 36, seed=203)     # two workgroups per CU: a ring of two stages
+    run_case(rmr, 4, 40, 40, 192, 256, 3, 1, True, False, tile=SB + 18, seed=204)   # fused head conv shape
+    run_case(rmr, 1, 20, 20, 1152, 576, 1, 1, True, False, tile=SB + 3, seed=205)   # SPPF cv2: 36 units
+    run_case(rmr, 4, 40, 40, 768, 384, 1, 1, True, False, tile=SB + 19, seed=206)   # C2f cv2
+    run_case(rmr, 1, 80, 80, 192, 384, 3, 2, True, False, tile=SB + 7, seed=207)    # model.5: 54 units, strided
+    run_case(rmr, 1, 40, 40, 64, 64, 1, 1, False, False, tile=SB + 7, seed=208)     # DFL conv: bias only
+    run_case(rmr, 1, 5, 5, 32, 96, 3, 1, False, False, tile=SB + 22, seed=209)      # tile far larger than the image
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 4, 4, 48), np.float32), np.zeros((96, 48, 3, 3), np.float32), None, 1, 1, False, tile=SB)   # Cin % 32
+    with pytest.raises(rmr.InvalidArgument):
+        rmr.conv2d(np.zeros((1, 8, 8, 64), np.float32), np.zeros((64, 64, 3, 3), np.float32), None, 2, 1, False, tile=SB)   # halo form, strided layer
+
+
 def test_conv_g32_every_tile(rmr):
     # the gathered form of conv_t32 (conv_g32.hip, ids 950..): 1x1 layers and 3x3 layers of any stride, one
     # (tap, 32-channel chunk) stage = the tile's pixel rows at that tap + the weight slice, padding as
