@@ -639,7 +639,7 @@ rmr_status rmr_conv_bench(int device, int n, int h, int w, int cin, int cout, in
             for (size_t i = 0; i + 15 < st.size(); i += 16)
                 if (st[i]) t0 = t0 < 0 ? st[i] : std::min(t0, st[i]), ++wgs;
             static const char* const what[16] = {"entry", "DMAs issued", "stage 0 landed", "last stage landed", "K loop done", "reduced", "epilogue issued", "stores done",
-                                                 "stage 0", "stage 1", "stage 2", "stage 3", "stage 4", "stage 5", "stage 6", "stage 7"};
+                                                 "stage 0", "stage 1", "stage 2", "stage 3", "stage 0 waited for", "fragment constants", "epilogue preloads", "DMA tables"};
             for (int k = 0; k < 16 && wgs; ++k) {
                 std::vector<double> v;
                 for (size_t i = 0; i + 15 < st.size(); i += 16)

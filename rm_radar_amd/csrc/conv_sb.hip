@@ -97,9 +97,15 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
 //     wait behind a stage is a multiple of one wave-uniform number (a loop of scalar branches had cost 170 cycles per DMA);
 //   * bias and shortcut are fetched BEFORE the first DMA (loads retire in order: they have landed with stage 0), the
 //     epilogue is arithmetic and stores.
-template <int WM, int WN, int WK, int MREP, int NREP, bool GATHER, int KM>
+// LW: 0 = every wave issues its share of the DMAs and computes; 4 = the first four waves of the workgroup (one per SIMD) only
+// issue DMAs, three stages ahead of the one the other WM * WN * WK waves compute: a wave that issues a stage's DMAs is held
+// at the address unit for 0.25 us (16 cycles per instruction and CU), which the symmetric form pays between the MFMAs of
+// every stage; a loader wave held there leaves its SIMD's issue slots to the computing wave beside it.
+template <int WM, int WN, int WK, int MREP, int NREP, bool GATHER, int KM, int LW>
 __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, const int m0, const int n0, unsigned char* smem, const unsigned lds0) {
-    constexpr int NW = WM * WN * WK;
+    constexpr int NC = WM * WN * WK;          // computing waves
+    constexpr int NW = LW ? LW : NC;          // waves that issue DMAs
+    constexpr int NT = LW + NC;               // waves of the workgroup
     constexpr int BM = WM * MREP * 32;
     constexpr int BN = WN * NREP * 32;
     constexpr int NB = BN / 16;   // weight DMA blocks per unit
@@ -123,7 +129,9 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     const unsigned in_lim = a.in_bytes, wt_lim = a.wt_t32_bytes;
 #endif
     stamp(0);
-    const int wk = wave % WK, wmn = wave / WK;
+    const bool loader = LW > 0 && wave < LW;   // a wave that only issues DMAs
+    const int cw = loader ? 0 : wave - LW;      // the computing wave's index
+    const int wk = cw % WK, wmn = cw / WK;
     const int wm = wmn / WN, wn = wmn % WN;
     const int W = a.W;
     const int npix = a.N * a.H * a.W;
@@ -141,7 +149,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     };
     float4 bias[NREP][4];
     u32x4 rres[MREP][NREP][2];
-    if (wide && wk == 0) {
+    if (wide && wk == 0 && !loader) {
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
 #pragma unroll
@@ -160,6 +168,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
         }
     }
 
+    stamp(14);
     const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu), sgpr(in_lim), sgpr(0x00020000u)};
     const u32x4 wt_rsrc = {sgpr((unsigned)(size_t)a.wt_t32), sgpr((unsigned)((size_t)a.wt_t32 >> 32) & 0xffffu), sgpr(wt_lim), sgpr(0x00020000u)};
 
@@ -274,14 +283,37 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
         }
     };
 
-    // ---- everything the ring holds goes in flight before anything else --------------------------------------------------
-    const int first = min(g.ns, g.stages);
-    for (int s = 0; s < first; ++s) issue(s, s);
+    stamp(15);
+    // ---- the first two stages go in flight before anything else; the rest is topped up two stages ahead of the one being
+    // waited for (the DMA instructions of a whole operand set take 1.2 us to ISSUE -- 16 cycles each at the CU's address unit --
+    // so a wave that issued everything first started its first MFMA 2.8 us into the kernel)
+    constexpr int LOOKAHEAD = LW ? 3 : 2;
+    int issued = 0, islot = 0;   // stages issued so far, ring slot of the next one
+    const auto top_up = [&](int limit) {
+        while (issued < g.stages && issued <= limit) {
+            issue(issued, islot);
+            ++issued;
+            islot = islot + 1 == g.ns ? 0 : islot + 1;
+        }
+    };
+    if (LW == 0 || loader) top_up(min(LOOKAHEAD, g.ns) - 1);
     stamp(1);
     // the zero KiB (surplus DMAs write zeros there as well, which keeps it zero)
-    for (int i = tid; i < 64; i += NW * 64) *(u32x4*)(smem + g.zero_off + i * 16) = u32x4{0, 0, 0, 0};
+    for (int i = tid; i < 64; i += NT * 64) *(u32x4*)(smem + g.zero_off + i * 16) = u32x4{0, 0, 0, 0};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave reaches the first barrier
 
+    if constexpr (LW > 0) {
+        if (loader) {
+            // the loader's whole life: keep LOOKAHEAD stages ahead, report each stage to the computing waves through the barrier
+            __builtin_amdgcn_s_barrier();   // (the zero KiB)
+            for (int s = 0; s < g.stages; ++s) {
+                top_up(min(s + LOOKAHEAD, s + g.ns - 2));
+                wait_vm_dyn(min((issued - 1 - s) * d_stage, 63));
+                __builtin_amdgcn_s_barrier();   // stage s has landed; the computing waves are done with stage s - 1
+            }
+            return;
+        }
+    }
     // ---- fragment constants ----------------------------------------------------------------------------------------------
     const int fkey = (kq ^ ((fr >> 2) & 3)) << 4;   // 16-byte slot of K-step 0 in a row whose index is fr modulo 16
     int arow[MREP];                                  // halo form: LDS row of the centre tap; gathered form: the pixel row
@@ -303,7 +335,17 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     }
     const int wrow = (wn * NREP * 32 + fr) * 64 + fkey;   // + j * 2048: fragment j of the weight rows
 
-    constexpr int NACC = MREP * NREP == 1 ? 2 : 1;   // accumulator sets (K-step parity where a wave tile is one fragment)
+    // accumulator sets: four independent MFMA chains per wave where the registers allow (a 32x32x16 MFMA has a latency of 16
+    // passes; chained on one accumulator the six MFMAs of a stage took 0.3 us).  Unit parity and K-step parity choose the set.
+    // GS: units whose fragments are read together, ahead of their MFMAs -- as many as the wave's register budget holds.
+    constexpr int MAXV = NT <= 4 ? 512 : NT <= 8 ? 256 : NT <= 12 ? 168 : 128;
+    constexpr int FRAGS = MREP * NREP;
+    constexpr int NACC_WANT = FRAGS == 1 ? 4 : FRAGS < 4 ? 2 : 1;
+    constexpr int OTHER = 56 + NREP * 16 + FRAGS * 8;   // addresses and tables, the epilogue's bias and shortcut registers
+    constexpr int NACC = NACC_WANT * FRAGS * 16 + OTHER + 2 * (MREP + NREP) * 8 <= MAXV ? NACC_WANT : NACC_WANT > 2 ? 2 : 1;
+    constexpr int GS_FIT = (MAXV - NACC * FRAGS * 16 - OTHER) / ((MREP + NREP) * 8);
+    constexpr int GS_CAP = 16 / (MREP + NREP);
+    constexpr int GS = GS_FIT < 1 ? 1 : (GS_FIT < GS_CAP ? (GS_FIT < KM ? GS_FIT : KM) : (GS_CAP < KM ? GS_CAP : KM));
     floatx16 acc[NACC][MREP][NREP];
 #pragma unroll
     for (int c = 0; c < NACC; ++c)
@@ -314,17 +356,23 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
+    stamp(13);
+    if constexpr (LW > 0) __builtin_amdgcn_s_barrier();   // pairs with the loaders' first barrier
     // ---- the stages ----------------------------------------------------------------------------------------------------------
     int slot = 0;          // ring slot of stage s
     for (int s = 0; s < g.stages; ++s) {
-        // stages issued so far: 0 .. hi; those behind s may still be in flight (d_stage DMAs of this wave each)
-        const int hi = min(s == 0 ? first - 1 : s + g.ns - 2, g.stages - 1);
-        wait_vm_dyn(min((hi - s) * d_stage, 63));
+        // a stage may be issued once every wave is done with the stage whose slot it takes: up to s + ns - 2 before the barrier
+        // of iteration s, up to s + ns - 1 behind it
+        if constexpr (LW == 0) {
+            top_up(min(s + LOOKAHEAD, s + g.ns - 2));
+            wait_vm_dyn(min((issued - 1 - s) * d_stage, 63));   // the stages behind s may still be in flight (d_stage DMAs of this wave each)
+        }
+        if (s == 0) stamp(12);
         __builtin_amdgcn_s_barrier();   // stage s has landed for every wave, and every wave is done with stage s - 1
         if (s == 0) stamp(2);
         if (s == g.stages - 1) stamp(3);
-        if (s < 8) stamp(8 + s);
-        if (s >= 1 && s - 1 + g.ns < g.stages) issue(s - 1 + g.ns, slot == 0 ? g.ns - 1 : slot - 1);
+        if (s < 4) stamp(8 + s);
+        if constexpr (LW == 0) top_up(min(s + LOOKAHEAD, s + g.ns - 1));
         const int sb = slot * g.stage_bytes;
         const int nu = GATHER ? (s == g.stages - 1 ? units_last : g.units) : 9;
 #ifdef RMR_SB_TIMING
@@ -335,7 +383,6 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
 #endif
         // GS units at a time: every fragment read of the group is issued before its first MFMA (left alone the compiler keeps
         // one read in flight and every MFMA waits for the LDS latency of its own operands)
-        constexpr int GS = KM * (MREP + NREP) <= 12 ? KM : (12 / (MREP + NREP) > 0 ? 12 / (MREP + NREP) : 1);
 #pragma unroll
         for (int k0 = 0; k0 < KM; k0 += GS) {
             half8 x0[GS][MREP], x1[GS][MREP], w0[GS][NREP], w1[GS][NREP];
@@ -382,21 +429,32 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
 #pragma unroll
                 for (int i = 0; i < MREP; ++i)
 #pragma unroll
-                    for (int j = 0; j < NREP; ++j) acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kk][j], x0[kk][i], acc[0][i][j], 0, 0, 0);
+                    for (int j = 0; j < NREP; ++j) {
+                        constexpr int c0 = 0;
+                        const int c = NACC == 4 ? 2 * ((k0 + kk) & 1) : c0;
+                        acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kk][j], x0[kk][i], acc[c][i][j], 0, 0, 0);
+                    }
 #pragma unroll
                 for (int i = 0; i < MREP; ++i)
 #pragma unroll
                     for (int j = 0; j < NREP; ++j)
-                        acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kk][j], x1[kk][i], acc[NACC - 1][i][j], 0, 0, 0);
+                    {
+                        const int c = NACC == 4 ? 2 * ((k0 + kk) & 1) + 1 : NACC - 1;
+                        acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kk][j], x1[kk][i], acc[c][i][j], 0, 0, 0);
+                    }
             }
             if (k0 + GS < KM) __builtin_amdgcn_sched_barrier(0);
         }
         slot = slot + 1 == g.ns ? 0 : slot + 1;
     }
-    if constexpr (NACC == 2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][0][r] += acc[1][0][0][r];
-    }
+    for (int c = 1; c < NACC; ++c)
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][i][j][r] += acc[c][i][j][r];
 
     stamp(4);
     // ---- the K shares of a wave tile meet in LDS (the ring is free now), summed in wave order -----------------------------------
@@ -499,8 +557,8 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
 #endif
 }
 
-template <int WM, int WN, int WK, int MREP, int NREP, bool GATHER, int KM>
-__global__ __launch_bounds__(WM* WN* WK * 64) void conv_sb_kernel(const ConvArgs a, const SbGeom g) {
+template <int WM, int WN, int WK, int MREP, int NREP, bool GATHER, int KM, int LW>
+__global__ __launch_bounds__((WM * WN * WK + LW) * 64) void conv_sb_kernel(const ConvArgs a, const SbGeom g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
     // tile of this workgroup: the workgroups of one XCD (blockIdx & 7) take a contiguous range of tile ids, so that the tiles
@@ -510,19 +568,20 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_sb_kernel(const ConvArgs
     const int xcd = blockIdx.x & 7;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     const int mi = g.n_inner ? lid / g.nt : lid % g.mt, ni = g.n_inner ? lid % g.nt : lid / g.mt;
-    sb_tile<WM, WN, WK, MREP, NREP, GATHER, KM>(a, g, mi * (WM * MREP * 32), ni * (WN * NREP * 32), smem, lds0);
+    sb_tile<WM, WN, WK, MREP, NREP, GATHER, KM, LW>(a, g, mi * (WM * MREP * 32), ni * (WN * NREP * 32), smem, lds0);
 }
 
 struct SbVariant {
-    int bm, bn, wk, km, threads, wgs_per_cu;
+    int bm, bn, wk, km, threads, wgs_per_cu, loaders;
     bool gather;
     void (*kernel)(const ConvArgs, const SbGeom);
 };
 
 // halo form: KM = ceil(9 / WK) taps per wave and stage; gathered form: KG units per wave and stage (a stage = KG * WK units)
-#define SB2(WM, WN, WK, MR, NR, KG, WPC)                                                                                              \
-    {WM * MR * 32, WN * NR * 32, WK, (9 + WK - 1) / WK, WM * WN * WK * 64, WPC, false, conv_sb_kernel<WM, WN, WK, MR, NR, false, (9 + WK - 1) / WK>}, \
-    {WM * MR * 32, WN * NR * 32, WK, KG, WM * WN * WK * 64, WPC, true, conv_sb_kernel<WM, WN, WK, MR, NR, true, KG>}
+#define SB3(WM, WN, WK, MR, NR, KG, WPC, LW)                                                                                                          \
+    {WM * MR * 32, WN * NR * 32, WK, (9 + WK - 1) / WK, (WM * WN * WK + LW) * 64, WPC, LW, false, conv_sb_kernel<WM, WN, WK, MR, NR, false, (9 + WK - 1) / WK, LW>}, \
+    {WM * MR * 32, WN * NR * 32, WK, KG, (WM * WN * WK + LW) * 64, WPC, LW, true, conv_sb_kernel<WM, WN, WK, MR, NR, true, KG, LW>}
+#define SB2(WM, WN, WK, MR, NR, KG, WPC) SB3(WM, WN, WK, MR, NR, KG, WPC, 0)
 
 // even ids: halo form, odd ids: the gathered form of the same tile
 const SbVariant kSbVariants[] = {
@@ -548,6 +607,15 @@ const SbVariant kSbVariants[] = {
     SB2(2, 1, 3, 2, 1, 2, 2),   // 36 / 37: 128 x 32
     SB2(2, 2, 2, 2, 1, 2, 2),   // 38 / 39: 128 x 64, eight waves
     SB2(4, 1, 2, 1, 3, 2, 2),   // 40 / 41: 128 x 96, eight waves
+    // four loader waves beside the computing waves
+    SB3(2, 1, 3, 1, 1, 3, 1, 4),   // 42 / 43:  64 x 32, 4 + 6 waves
+    SB3(2, 1, 4, 1, 1, 2, 1, 4),   // 44 / 45:  64 x 32, 4 + 8 waves
+    SB3(1, 1, 3, 1, 1, 3, 1, 4),   // 46 / 47:  32 x 32, 4 + 3 waves
+    SB3(4, 1, 2, 1, 1, 2, 1, 4),   // 48 / 49: 128 x 32, 4 + 8 waves
+    SB3(2, 2, 2, 1, 1, 2, 1, 4),   // 50 / 51:  64 x 64, 4 + 8 waves
+    SB3(2, 2, 2, 2, 1, 2, 1, 4),   // 52 / 53: 128 x 64, 4 + 8 waves
+    SB3(4, 1, 1, 1, 3, 4, 1, 4),   // 54 / 55: 128 x 96, 4 + 4 waves
+    SB3(4, 2, 1, 1, 1, 4, 1, 4),   // 56 / 57: 128 x 64, 4 + 8 waves, no K sharing
 };
 constexpr int kNumSbVariants = sizeof(kSbVariants) / sizeof(kSbVariants[0]);
 
@@ -566,13 +634,14 @@ int sb_geometry(const ConvArgs& a, const SbVariant& v, SbGeom& g) {
     } else {
         const int unit_bytes = (v.bm + v.bn) * 64;
         g.units = std::min(v.km * v.wk, g.total_units);
-        // more than one stage: the ring holds at least two (fewer units per wave and stage where it would not)
-        while (g.units > v.wk && g.units < g.total_units && 2 * g.units * unit_bytes > budget) g.units -= v.wk;
+        // more than one stage: the ring holds at least two (three with loader waves; fewer units per wave and stage where it would not)
+        while (g.units > v.wk && g.units < g.total_units && (v.loaders ? 3 : 2) * g.units * unit_bytes > budget) g.units -= v.wk;
         g.stage_bytes = g.units * unit_bytes;
         g.stages = (g.total_units + g.units - 1) / g.units;
     }
     g.ns = std::min(g.stages, budget / g.stage_bytes);
     if (g.ns < 1 || (g.ns < 2 && g.stages > 1)) return 0;
+    if (v.loaders && g.ns < 3 && g.stages > g.ns) return 0;   // loaders run ahead of the computing waves: a ring of three at least
     g.mt = (a.M + v.bm - 1) / v.bm;
     g.nt = a.Cout_pad / v.bn;
     // what the tiles of an XCD share: with the channel tile innermost an XCD reads its pixel rows once and every weight

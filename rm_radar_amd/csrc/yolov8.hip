@@ -978,7 +978,7 @@ bool Yolov8::choice_supported(const ConvArgs& a, int choice) const {
 // (the version moves whenever the set of candidate kernels does: 11 = conv_g32 added, 12 = conv_w1d, 13 = split-K conv_t32, 14 = conv_t32 tiles 13-14,
 // 15 = conv_wsp (conv_ws variants 12-16), conv_w1d out of the product build, 16 = fused bottlenecks (conv_wsf, 340.. + 399),
 // 17 = the small-batch family conv_sb (100000..))
-static constexpr int kTuneFileVersion = 16;   // -> 17 with the regenerated plans
+static constexpr int kTuneFileVersion = 17;
 int Yolov8::tune_file_version() { return kTuneFileVersion; }
 static std::string device_tag(int device) {
     hipDeviceProp_t p;

@@ -23,7 +23,7 @@ if not os.path.exists(car):
     W.make_synthetic_pack(car, "m", 1, seed=1, cls_bias=-6.0)
     W.make_synthetic_pack(armor, "m", 12, seed=2, cls_bias=-6.0)
 import bench  # noqa: E402
-plan = bench.apply_plan(bench.parse([]), (car, armor))   # the committed pinned plan (profiles/plans/), when there is one
+plan = bench.apply_plan(bench.parse(sys.argv[3:4] and ["--plan", sys.argv[3]] or []), (car, armor))   # the committed pinned plan (profiles/plans/), when there is one; argv[3] = tune: autotune here
 rng = np.random.default_rng(0)
 img = scenes.synthetic_image(0)
 cloud = scenes.make_cloud(rng, 30000, scenes.K640, scenes.SAMPLE_L2C, (640, 640), [((100, 300, 120, 90), 2000, 200)])
