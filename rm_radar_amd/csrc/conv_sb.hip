@@ -55,6 +55,8 @@ struct SbGeom {
 
 // LDS-DMA with the wait states a freshly written scalar operand needs in front of a vector-memory instruction
 __device__ __forceinline__ void dma_sb(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);   // wave-uniform by construction; the compiler cannot always tell
+    soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
     asm volatile("s_nop 3\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
@@ -97,8 +99,9 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
 //     wait behind a stage is a multiple of one wave-uniform number (a loop of scalar branches had cost 170 cycles per DMA);
 //   * bias and shortcut are fetched BEFORE the first DMA (loads retire in order: they have landed with stage 0), the
 //     epilogue is arithmetic and stores.
-// LW: 0 = every wave issues its share of the DMAs and computes; 4 = the first four waves of the workgroup (one per SIMD) only
-// issue DMAs, three stages ahead of the one the other WM * WN * WK waves compute: a wave that issues a stage's DMAs is held
+// LW: 0 = every wave issues its share of the DMAs and computes; 4 / 8 = the first LW waves of the workgroup (one / two per SIMD)
+// only issue DMAs, a few stages ahead of the one the other WM * WN * WK waves compute (a wave gets an LDS-DMA instruction out
+// every ~130 cycles, the CU's address unit takes one every 16: it takes eight issuing waves to keep it busy): a wave that issues a stage's DMAs is held
 // at the address unit for 0.25 us (16 cycles per instruction and CU), which the symmetric form pays between the MFMAs of
 // every stage; a loader wave held there leaves its SIMD's issue slots to the computing wave beside it.
 template <int WM, int WN, int WK, int MREP, int NREP, bool GATHER, int KM, int LW>
@@ -121,7 +124,8 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     // under RMR_CONV_TIMING=1; RMR_SB_ABLATE (bit 0: no fragment reads / MFMAs, 1: weight DMAs out of range, 2: input DMAs out
     // of range) arrives in g.ablate
     const auto stamp = [&](int k) {
-        if (a.timing && tid == 0) a.timing[(size_t)blockIdx.x * 16 + k] = (long long)__builtin_amdgcn_s_memrealtime();
+        // the DMA side's stamps (0, 1, 14, 15) by wave 0, the others by the first computing wave
+        if (a.timing && tid == ((k == 0 || k == 1 || k >= 14) ? 0 : LW * 64)) a.timing[(size_t)blockIdx.x * 16 + k] = (long long)__builtin_amdgcn_s_memrealtime();
     };
     const unsigned in_lim = (g.ablate & 4) ? 0u : a.in_bytes, wt_lim = (g.ablate & 2) ? 0u : a.wt_t32_bytes;
 #else
@@ -147,13 +151,18 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
         const long b = rows_left * cs * 2;
         return (unsigned)(b <= 0 ? 0 : b > 0xfffffff0l ? 0xfffffff0l : b);
     };
-    float4 bias[NREP][4];
-    u32x4 rres[MREP][NREP][2];
-    if (wide && wk == 0 && !loader) {
+    // with K shared by two or more waves the wide epilogue is shared as well: wave wk = 0 / 1 of a wave tile finishes channel
+    // groups 0-1 / 2-3 (gp = 0 / 1) of every fragment
+    constexpr int EW = WK >= 2 ? 2 : 1;        // waves of a wave tile that run the wide epilogue
+    constexpr int GPN = EW == 2 ? 1 : 2;       // 16-channel halves of a fragment each of them finishes
+    const int gp0 = EW == 2 ? wk : 0;
+    float4 bias[NREP][GPN * 2];
+    u32x4 rres[MREP][NREP][GPN];
+    if (wide && wk < EW && !loader) {
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) bias[j][gq] = *(const float4*)(a.bias + nw0 + j * 32 + gq * 8 + kq * 4);
+            for (int gq = 0; gq < GPN * 2; ++gq) bias[j][gq] = *(const float4*)(a.bias + nw0 + j * 32 + (gp0 * 2 + gq) * 8 + kq * 4);
         if (a.res) {
             const __amdgpu_buffer_rsrc_t res_rsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)a.res + (long)mw0 * a.res_cs), 0, view_bytes(a.res_cs), 0x00020000);
@@ -163,8 +172,8 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
 #pragma unroll
                 for (int j = 0; j < NREP; ++j)
 #pragma unroll
-                    for (int gp = 0; gp < 2; ++gp)
-                        rres[i][j][gp] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_lane + (unsigned)(i * 32 * a.res_cs + j * 32 + gp * 16) * 2u, 0, 0);
+                    for (int gg = 0; gg < GPN; ++gg)
+                        rres[i][j][gg] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_lane + (unsigned)(i * 32 * a.res_cs + j * 32 + (gp0 + gg) * 16) * 2u, 0, 0);
         }
     }
 
@@ -201,46 +210,53 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     bool g_pix[GCNT];
     unsigned g_base[GCNT];   // per lane: byte offset of the pixel's tap (0, 0), channel chunk 0
     unsigned g_ok[GCNT];     // per lane: bit 3 ky + kx = that tap lies inside the image
-    if constexpr (!GATHER) {
+    // (the waves that never issue a DMA skip this: LW > 0 and not a loader)
 #pragma unroll
-        for (int i = 0; i < WCNT; ++i) {
-            const int wq = wave + i * NW;
-            const int t = wq / NB, b = wq - t * NB;
-            w_src[i] = (unsigned)(t * nblk_all + n0_16 + b) * 1024u;
-            w_dst[i] = wq < 9 * NB ? (unsigned)(a_bytes + wq * 1024) : 0u;
-            if (i == WCNT - 1) w_voff_last = wq < 9 * NB ? lane16 : OOB;
-        }
-    } else {
+    for (int i = 0; i < WCNT; ++i) w_src[i] = 0u, w_dst[i] = 0u;
 #pragma unroll
-        for (int i = 0; i < GCNT; ++i) {
-            const int q = wave + i * NW;
-            const int u = q / (PB + NB), r = q - u * (PB + NB);
-            g_unit[i] = u;
-            g_pix[i] = r < PB;
-            g_dst[i] = (unsigned)(u * UNIT_BYTES + r * 1024);
-            g_wsrc[i] = (unsigned)(n0_16 + r - PB) * 1024u;
-            const int m = m0 + r * 16 + lrow;
-            int ox = m, oy = 0, img = 0;
-            if (!(a.KH == 1 && a.stride == 1)) {
-                ox = m % a.Wo;
-                const int qq = m / a.Wo;
-                oy = qq % a.Ho, img = qq / a.Ho;
+    for (int i = 0; i < GCNT; ++i) g_unit[i] = 0, g_dst[i] = 0u, g_wsrc[i] = 0u, g_pix[i] = false, g_base[i] = 0u, g_ok[i] = 0u;
+    if (LW == 0 || loader) {
+        if constexpr (!GATHER) {
+#pragma unroll
+            for (int i = 0; i < WCNT; ++i) {
+                const int wq = wave + i * NW;
+                const int t = wq / NB, b = wq - t * NB;
+                w_src[i] = (unsigned)(t * nblk_all + n0_16 + b) * 1024u;
+                w_dst[i] = wq < 9 * NB ? (unsigned)(a_bytes + wq * 1024) : 0u;
+                if (i == WCNT - 1) w_voff_last = wq < 9 * NB ? lane16 : OOB;
             }
-            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            unsigned ok = 0;
-            if (r < PB && m < a.M) {
-                if (a.KH == 1) {
-                    ok = 1u;
-                } else {
+        } else {
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx)
-                            if (iy0 + ky >= 0 && iy0 + ky < a.H && ix0 + kx >= 0 && ix0 + kx < W) ok |= 1u << (ky * 3 + kx);
+            for (int i = 0; i < GCNT; ++i) {
+                const int q = wave + i * NW;
+                const int u = q / (PB + NB), r = q - u * (PB + NB);
+                g_unit[i] = u;
+                g_pix[i] = r < PB;
+                g_dst[i] = (unsigned)(u * UNIT_BYTES + r * 1024);
+                g_wsrc[i] = (unsigned)(n0_16 + r - PB) * 1024u;
+                const int m = m0 + r * 16 + lrow;
+                int ox = m, oy = 0, img = 0;
+                if (!(a.KH == 1 && a.stride == 1)) {
+                    ox = m % a.Wo;
+                    const int qq = m / a.Wo;
+                    oy = qq % a.Ho, img = qq / a.Ho;
                 }
+                const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                unsigned ok = 0;
+                if (r < PB && m < a.M) {
+                    if (a.KH == 1) {
+                        ok = 1u;
+                    } else {
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx)
+                                if (iy0 + ky >= 0 && iy0 + ky < a.H && ix0 + kx >= 0 && ix0 + kx < W) ok |= 1u << (ky * 3 + kx);
+                    }
+                }
+                g_ok[i] = ok;
+                g_base[i] = (a.KH == 1 && a.stride == 1) ? (unsigned)m * cs2 + in_cb : (unsigned)((img * a.H + iy0) * W + ix0) * cs2 + in_cb;
             }
-            g_ok[i] = ok;
-            g_base[i] = (a.KH == 1 && a.stride == 1) ? (unsigned)m * cs2 + in_cb : (unsigned)((img * a.H + iy0) * W + ix0) * cs2 + in_cb;
         }
     }
     const int d_stage = GATHER ? GCNT : WCNT + na_w;   // DMAs per wave and stage
@@ -287,7 +303,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     // ---- the first two stages go in flight before anything else; the rest is topped up two stages ahead of the one being
     // waited for (the DMA instructions of a whole operand set take 1.2 us to ISSUE -- 16 cycles each at the CU's address unit --
     // so a wave that issued everything first started its first MFMA 2.8 us into the kernel)
-    constexpr int LOOKAHEAD = LW ? 3 : 2;
+    constexpr int LOOKAHEAD = 2;
     int issued = 0, islot = 0;   // stages issued so far, ring slot of the next one
     const auto top_up = [&](int limit) {
         while (issued < g.stages && issued <= limit) {
@@ -306,10 +322,12 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
         if (loader) {
             // the loader's whole life: keep LOOKAHEAD stages ahead, report each stage to the computing waves through the barrier
             __builtin_amdgcn_s_barrier();   // (the zero KiB)
+            // (stage s + 1 is in flight while stage s is waited for, so the address unit never idles; more stages ahead only
+            // delay the report of stage 0: with three the first MFMA started 2.4 us into the kernel)
             for (int s = 0; s < g.stages; ++s) {
-                top_up(min(s + LOOKAHEAD, s + g.ns - 2));
                 wait_vm_dyn(min((issued - 1 - s) * d_stage, 63));
                 __builtin_amdgcn_s_barrier();   // stage s has landed; the computing waves are done with stage s - 1
+                top_up(min(s + LOOKAHEAD, s + g.ns - 1));
             }
             return;
         }
@@ -341,7 +359,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     constexpr int MAXV = NT <= 4 ? 512 : NT <= 8 ? 256 : NT <= 12 ? 168 : 128;
     constexpr int FRAGS = MREP * NREP;
     constexpr int NACC_WANT = FRAGS == 1 ? 4 : FRAGS < 4 ? 2 : 1;
-    constexpr int OTHER = 56 + NREP * 16 + FRAGS * 8;   // addresses and tables, the epilogue's bias and shortcut registers
+    constexpr int OTHER = 24 + NREP * 16 + FRAGS * 8 + (GATHER ? 2 * GCNT + 16 : (FRAGS > 2 ? 24 : 0));   // addresses and tables, the epilogue's bias and shortcut registers
     constexpr int NACC = NACC_WANT * FRAGS * 16 + OTHER + 2 * (MREP + NREP) * 8 <= MAXV ? NACC_WANT : NACC_WANT > 2 ? 2 : 1;
     constexpr int GS_FIT = (MAXV - NACC * FRAGS * 16 - OTHER) / ((MREP + NREP) * 8);
     constexpr int GS_CAP = 16 / (MREP + NREP);
@@ -457,12 +475,13 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
                 for (int r = 0; r < 16; ++r) acc[0][i][j][r] += acc[c][i][j][r];
 
     stamp(4);
-    // ---- the K shares of a wave tile meet in LDS (the ring is free now), summed in wave order -----------------------------------
+    // ---- the K shares of a wave tile meet in LDS (the ring is free now): every wave leaves its partial tile there, the waves
+    // that run the epilogue sum the shares of THEIR channel groups in wave order (deterministic)
     if constexpr (WK > 1) {
         constexpr int FRAG = MREP * NREP * 4096;   // bytes of one wave's accumulators
         __builtin_amdgcn_s_barrier();
-        if (wk > 0) {
-            unsigned char* const dst = smem + ((wk - 1) * WM * WN + wmn) * FRAG + lane * 16;
+        {
+            unsigned char* const dst = smem + (wk * WM * WN + wmn) * FRAG + lane * 16;
 #pragma unroll
             for (int i = 0; i < MREP; ++i)
 #pragma unroll
@@ -473,27 +492,34 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
                             make_float4(acc[0][i][j][4 * r], acc[0][i][j][4 * r + 1], acc[0][i][j][4 * r + 2], acc[0][i][j][4 * r + 3]);
         }
         __builtin_amdgcn_s_barrier();
-        if (wk > 0) return;
+        if (wk >= (wide ? EW : 1)) return;
+        // float4 r of a fragment = registers 4 r .. 4 r + 3 = channel group r: the wide epilogue's wave takes r = 2 gp0, 2 gp0 + 1
+        const int r_lo = wide ? 2 * gp0 : 0, r_n = wide ? 2 * GPN : 4;
 #pragma unroll
-        for (int z = 1; z < WK; ++z) {
-            const unsigned char* const src = smem + ((z - 1) * WM * WN + wmn) * FRAG + lane * 16;
+        for (int i = 0; i < MREP; ++i)
 #pragma unroll
-            for (int i = 0; i < MREP; ++i)
+            for (int j = 0; j < NREP; ++j)
 #pragma unroll
-                for (int j = 0; j < NREP; ++j)
+                for (int rr = 0; rr < 4; ++rr) {
+                    if (rr >= r_n) continue;
+                    const int r = r_lo + rr;
+                    float4 sum = *(const float4*)(smem + (0 * WM * WN + wmn) * FRAG + lane * 16 + ((i * NREP + j) * 4 + r) * 1024);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float4 p = *(const float4*)(src + ((i * NREP + j) * 4 + r) * 1024);
-                        acc[0][i][j][4 * r] += p.x, acc[0][i][j][4 * r + 1] += p.y, acc[0][i][j][4 * r + 2] += p.z, acc[0][i][j][4 * r + 3] += p.w;
+                    for (int z = 1; z < WK; ++z) {
+                        const float4 p = *(const float4*)(smem + (z * WM * WN + wmn) * FRAG + lane * 16 + ((i * NREP + j) * 4 + r) * 1024);
+                        sum.x += p.x, sum.y += p.y, sum.z += p.z, sum.w += p.w;
                     }
-        }
+                    const int q = rr;   // (r is a run-time value for the wide epilogue's second wave: its sums go to the registers of half 0)
+                    acc[0][i][j][4 * q] = sum.x, acc[0][i][j][4 * q + 1] = sum.y, acc[0][i][j][4 * q + 2] = sum.z, acc[0][i][j][4 * q + 3] = sum.w;
+                }
     }
     stamp(5);
     if (!wide) {
         epilogue<MREP, NREP, 0, false, true>(a, acc[0], smem, 0, 0, m0, n0, wm, wn, lane);
     } else {
         // conv_t32_common.h's wide epilogue with its loads hoisted to the top of the kernel: bias, SiLU, (+ shortcut in f32),
-        // one rounding, lane pairs (l, l + 32) exchange halves so that each stores 16 bytes (8 consecutive channels)
+        // one rounding, lane pairs (l, l + 32) exchange halves so that each stores 16 bytes (8 consecutive channels).  With K
+        // shared (WK > 1) this wave's half sits in registers 0 .. 7 of every fragment, otherwise half gg in registers 8 gg ..
         const __amdgpu_buffer_rsrc_t out_rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void*)((_Float16*)a.out + (long)mw0 * a.out_cs), 0, view_bytes(a.out_cs), 0x00020000);
         const unsigned out_lane = (unsigned)(fr * a.out_cs + a.out_co + nw0 + kq * 8) * 2u;
@@ -503,12 +529,12 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
 #pragma unroll
             for (int j = 0; j < NREP; ++j)
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
+                for (int gg = 0; gg < GPN; ++gg) {
                     float v[8];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const float4 b = bias[j][gp * 2 + h];
-                        const int r0 = (gp * 2 + h) * 4;
+                        const float4 b = bias[j][gg * 2 + h];
+                        const int r0 = (gg * 2 + h) * 4;
                         v[h * 4 + 0] = silu_t(acc[0][i][j][r0 + 0] + b.x);
                         v[h * 4 + 1] = silu_t(acc[0][i][j][r0 + 1] + b.y);
                         v[h * 4 + 2] = silu_t(acc[0][i][j][r0 + 2] + b.z);
@@ -530,7 +556,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
                             u32x4 u;
                             _Float16 h[8];
                         } rr;
-                        rr.u = rres[i][j][gp];
+                        rr.u = rres[i][j][gg];
 #pragma unroll
                         for (int r = 0; r < 8; ++r) o.h[r] = (_Float16)(v[r] + (float)rr.h[r]);
                     } else {
@@ -547,7 +573,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
                         o.w[2] = s0[1];
                         o.w[3] = s1[1];
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(i * 32 * a.out_cs + j * 32 + gp * 16) * 2u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(i * 32 * a.out_cs + j * 32 + (gp0 + gg) * 16) * 2u, 0, 0);
                 }
     }
     stamp(6);
@@ -606,16 +632,21 @@ const SbVariant kSbVariants[] = {
     SB2(2, 2, 3, 1, 1, 2, 2),   // 34 / 35:  64 x 64
     SB2(2, 1, 3, 2, 1, 2, 2),   // 36 / 37: 128 x 32
     SB2(2, 2, 2, 2, 1, 2, 2),   // 38 / 39: 128 x 64, eight waves
-    SB2(4, 1, 2, 1, 3, 2, 2),   // 40 / 41: 128 x 96, eight waves
     // four loader waves beside the computing waves
-    SB3(2, 1, 3, 1, 1, 3, 1, 4),   // 42 / 43:  64 x 32, 4 + 6 waves
-    SB3(2, 1, 4, 1, 1, 2, 1, 4),   // 44 / 45:  64 x 32, 4 + 8 waves
-    SB3(1, 1, 3, 1, 1, 3, 1, 4),   // 46 / 47:  32 x 32, 4 + 3 waves
-    SB3(4, 1, 2, 1, 1, 2, 1, 4),   // 48 / 49: 128 x 32, 4 + 8 waves
-    SB3(2, 2, 2, 1, 1, 2, 1, 4),   // 50 / 51:  64 x 64, 4 + 8 waves
-    SB3(2, 2, 2, 2, 1, 2, 1, 4),   // 52 / 53: 128 x 64, 4 + 8 waves
-    SB3(4, 1, 1, 1, 3, 4, 1, 4),   // 54 / 55: 128 x 96, 4 + 4 waves
-    SB3(4, 2, 1, 1, 1, 4, 1, 4),   // 56 / 57: 128 x 64, 4 + 8 waves, no K sharing
+    SB3(2, 1, 3, 1, 1, 3, 1, 4),   // 40 / 41:  64 x 32, 4 + 6 waves
+    SB3(2, 1, 4, 1, 1, 2, 1, 4),   // 42 / 43:  64 x 32, 4 + 8 waves
+    SB3(1, 1, 3, 1, 1, 3, 1, 4),   // 44 / 45:  32 x 32, 4 + 3 waves
+    SB3(4, 1, 2, 1, 1, 2, 1, 4),   // 46 / 47: 128 x 32, 4 + 8 waves
+    SB3(2, 2, 2, 1, 1, 2, 1, 4),   // 48 / 49:  64 x 64, 4 + 8 waves
+    SB3(2, 2, 2, 2, 1, 2, 1, 4),   // 50 / 51: 128 x 64, 4 + 8 waves
+    SB3(4, 1, 1, 1, 3, 4, 1, 4),   // 52 / 53: 128 x 96, 4 + 4 waves
+    SB3(4, 2, 1, 1, 1, 4, 1, 4),   // 54 / 55: 128 x 64, 4 + 8 waves, no K sharing
+    // eight loader waves
+    SB3(2, 1, 3, 1, 1, 3, 1, 8),   // 56 / 57:  64 x 32, 8 + 6 waves
+    SB3(2, 1, 2, 1, 1, 4, 1, 8),   // 58 / 59:  64 x 32, 8 + 4 waves
+    SB3(1, 1, 3, 1, 1, 3, 1, 8),   // 60 / 61:  32 x 32, 8 + 3 waves
+    SB3(4, 1, 2, 1, 1, 2, 1, 8),   // 62 / 63: 128 x 32, 8 + 8 waves
+    SB3(4, 2, 1, 1, 1, 4, 1, 8),   // 64 / 65: 128 x 64, 8 + 8 waves
 };
 constexpr int kNumSbVariants = sizeof(kSbVariants) / sizeof(kSbVariants[0]);
 
@@ -650,7 +681,7 @@ int sb_geometry(const ConvArgs& a, const SbVariant& v, SbGeom& g) {
     g.n_inner = in_bytes >= wt_bytes ? 1 : 0;
     g.zero_off = g.ns * g.stage_bytes;
     g.ablate = std::getenv("RMR_SB_ABLATE") ? std::atoi(std::getenv("RMR_SB_ABLATE")) : 0;   // read by development builds only
-    const int reduce_bytes = v.wk > 1 ? (v.wk - 1) * (v.bm / 32) * (v.bn / 32) * 4096 : 0;   // aliases the ring
+    const int reduce_bytes = v.wk > 1 ? v.wk * (v.bm / 32) * (v.bn / 32) * 4096 : 0;   // aliases the ring
     return std::max(g.zero_off + 1024, reduce_bytes);
 }
 

@@ -377,8 +377,9 @@ def test_conv_sb_every_variant(rmr):
     # small batches (conv_sb.hip): tiles of 32 x 32 ... 128 x 128 whose whole operand set is in flight at once; even variants =
     # halo form (3x3 / stride 1), odd variants = gathered form (1x1, strided 3x3); 3-12 waves, those of a wave tile share K
     tiles = [(32, 32), (64, 32), (32, 64), (64, 64), (128, 32), (64, 32), (64, 32), (128, 32), (128, 64), (128, 64), (128, 64),
-             (128, 96), (128, 96), (64, 32), (128, 64), (32, 32), (64, 32), (64, 64), (128, 32), (128, 64), (128, 96),
-             (64, 32), (64, 32), (32, 32), (128, 32), (64, 64), (128, 64), (128, 96), (128, 64)]   # 21..: four loader waves beside the computing waves
+             (128, 96), (128, 96), (64, 32), (128, 64), (32, 32), (64, 32), (64, 64), (128, 32), (128, 64),
+             (64, 32), (64, 32), (32, 32), (128, 32), (64, 64), (128, 64), (128, 96), (128, 64),   # 20..: four loader waves beside the computing waves
+             (64, 32), (64, 32), (32, 32), (128, 32), (128, 64)]                               # 28..: eight
     def ran(*args, **kw):   # a variant whose ring cannot hold two stages of a layer refuses it (the tuner never offers it there)
         try:
             run_case(rmr, *args, **kw)

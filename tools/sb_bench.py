@@ -30,7 +30,7 @@ LAYERS = [  # n, h, w, cin, cout, k, stride, res, the plan's kernels
     (4, 40, 40, 768, 384, 1, 1, 0, [20]),
 ]
 copies = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-nvar = 58
+nvar = 66
 
 
 def best(n, h, w, cin, cout, k, s, res, kid, reps=30):
