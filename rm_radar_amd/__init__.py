@@ -167,7 +167,8 @@ def pin_plan(tune_path, plan_path, batches):
             op, n, choice = (int(v) for v in line.split())
             # split-K (1000 * split + tile) reduces partial sums in an order that depends on the split: the
             # plan takes the same tile without it
-            choice %= 1000
+            if choice < 100000:   # (100000 + variant = the small-batch family conv_sb: no split-K form)
+                choice %= 1000
             if op not in best or n > best[op][0]:
                 best[op] = (n, choice)
     with open(plan_path, "w") as f:
