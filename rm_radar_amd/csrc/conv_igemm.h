@@ -173,6 +173,15 @@ int conv_sb_num_variants();
 ConvTile conv_sb_tile(int id);
 bool conv_sb_supported(const ConvArgs& a, int variant);  // variant < 0: the layer shape only
 void launch_conv_sb(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant);
+// n (2..8) INDEPENDENT layers in one launch of variant `variant` (the Detect head's branches; kernel ids kSbGroupBase + variant on
+// the first layer of a group, kGroupedAway on the others): the problem table (conv_sb_group_bytes(n) bytes, built on the host by
+// conv_sb_group_build) lives in device memory for as long as launches (or captured graphs) use it
+constexpr int kSbGroupBase = 200000;
+constexpr int kGroupedAway = 398;
+size_t conv_sb_group_bytes(int n);
+bool conv_sb_group_supported(const ConvArgs* args, int n, int variant);
+int conv_sb_group_build(const ConvArgs* args, int n, int variant, void* host_buf);
+void launch_conv_sb_group(DeviceCtx& ctx, hipStream_t stream, const ConvArgs* args, int n, const void* dev_probs, int variant);
 // the fp8 form (conv_t32f8.hip): e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4, f16 output
 int conv_t32f8_num_tiles();
 ConvTile conv_t32f8_tile(int id);

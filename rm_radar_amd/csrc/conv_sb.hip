@@ -597,16 +597,44 @@ __global__ __launch_bounds__((WM * WN * WK + LW) * 64) void conv_sb_kernel(const
     sb_tile<WM, WN, WK, MREP, NREP, GATHER, KM, LW>(a, g, mi * (WM * MREP * 32), ni * (WN * NREP * 32), smem, lds0);
 }
 
+// Several INDEPENDENT layers in one launch (the Detect head: the same depth of its six branches): problem p owns the tile ids
+// [tile0, tile0 + mt * nt).  A batch-1 layer is a fixed cost of launch, ramp and epilogue around very little arithmetic, so six
+// of them side by side cost little more than the largest one.
+struct SbProblem {
+    ConvArgs a;
+    SbGeom g;
+    int tile0;
+    int pad[3];
+};
+
+template <int WM, int WN, int WK, int MREP, int NREP, bool GATHER, int KM, int LW>
+__global__ __launch_bounds__((WM * WN * WK + LW) * 64) void conv_sb_group_kernel(const SbProblem* __restrict__ probs, const int n_probs, const int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
+    const int xcd = blockIdx.x & 7;
+    const int gid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    int p = 0;
+    for (int i = 1; i < n_probs; ++i)
+        if (gid >= probs[i].tile0) p = i;
+    const ConvArgs a = probs[p].a;
+    const SbGeom g = probs[p].g;
+    const int lid = gid - probs[p].tile0;
+    const int mi = g.n_inner ? lid / g.nt : lid % g.mt, ni = g.n_inner ? lid % g.nt : lid / g.mt;
+    sb_tile<WM, WN, WK, MREP, NREP, GATHER, KM, LW>(a, g, mi * (WM * MREP * 32), ni * (WN * NREP * 32), smem, lds0);
+}
+
 struct SbVariant {
     int bm, bn, wk, km, threads, wgs_per_cu, loaders;
     bool gather;
     void (*kernel)(const ConvArgs, const SbGeom);
+    void (*group_kernel)(const SbProblem*, int, int);
 };
 
 // halo form: KM = ceil(9 / WK) taps per wave and stage; gathered form: KG units per wave and stage (a stage = KG * WK units)
 #define SB3(WM, WN, WK, MR, NR, KG, WPC, LW)                                                                                                          \
-    {WM * MR * 32, WN * NR * 32, WK, (9 + WK - 1) / WK, (WM * WN * WK + LW) * 64, WPC, LW, false, conv_sb_kernel<WM, WN, WK, MR, NR, false, (9 + WK - 1) / WK, LW>}, \
-    {WM * MR * 32, WN * NR * 32, WK, KG, (WM * WN * WK + LW) * 64, WPC, LW, true, conv_sb_kernel<WM, WN, WK, MR, NR, true, KG, LW>}
+    {WM * MR * 32, WN * NR * 32, WK, (9 + WK - 1) / WK, (WM * WN * WK + LW) * 64, WPC, LW, false, conv_sb_kernel<WM, WN, WK, MR, NR, false, (9 + WK - 1) / WK, LW>, conv_sb_group_kernel<WM, WN, WK, MR, NR, false, (9 + WK - 1) / WK, LW>}, \
+    {WM * MR * 32, WN * NR * 32, WK, KG, (WM * WN * WK + LW) * 64, WPC, LW, true, conv_sb_kernel<WM, WN, WK, MR, NR, true, KG, LW>, conv_sb_group_kernel<WM, WN, WK, MR, NR, true, KG, LW>}
 #define SB2(WM, WN, WK, MR, NR, KG, WPC) SB3(WM, WN, WK, MR, NR, KG, WPC, 0)
 
 // even ids: halo form, odd ids: the gathered form of the same tile
@@ -674,7 +702,7 @@ int sb_geometry(const ConvArgs& a, const SbVariant& v, SbGeom& g) {
     if (g.ns < 1 || (g.ns < 2 && g.stages > 1)) return 0;
     if (v.loaders && g.ns < 3 && g.stages > g.ns) return 0;   // loaders run ahead of the computing waves: a ring of three at least
     g.mt = (a.M + v.bm - 1) / v.bm;
-    g.nt = a.Cout_pad / v.bn;
+    g.nt = (a.Cout_pad + v.bn - 1) / v.bn;   // (a last tile of 16 channels: f32 views only, the stores beyond Cout_pad are dropped)
     // what the tiles of an XCD share: with the channel tile innermost an XCD reads its pixel rows once and every weight
     // row; with the pixel tile innermost the other way round -- the larger operand is the one to share
     const double in_bytes = (double)a.N * a.H * a.W * a.Cin * 2, wt_bytes = (double)a.Cout_pad * a.K * 2;
@@ -697,7 +725,7 @@ bool conv_sb_supported(const ConvArgs& a, int variant) {
     if (variant >= kNumSbVariants) return false;
     const SbVariant& v = kSbVariants[variant];
     if (!v.gather && (a.KH != 3 || a.stride != 1 || a.Ho != a.H || a.Wo != a.W)) return false;
-    if (a.Cout_pad % v.bn) return false;
+    if (a.Cout_pad % v.bn && !(a.out32 && a.Cout_pad % 16 == 0 && v.bn == 32)) return false;   // the class logits: 16 channels
     SbGeom g;
     const int lds = sb_geometry(a, v, g);
     if (lds <= 0 || lds > 160 * 1024 / v.wgs_per_cu) return false;
@@ -731,6 +759,69 @@ void launch_conv_sb(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
     }
     ProfScope ps(ctx.prof, stream, pname, flops, bytes);
     v.kernel<<<g.mt * g.nt, v.threads, lds, stream>>>(a, g);
+    RMR_HIP(hipGetLastError());
+}
+
+// ---- several independent layers in one launch -------------------------------------------------------------------------
+size_t conv_sb_group_bytes(int n) { return (size_t)n * sizeof(SbProblem); }
+
+bool conv_sb_group_supported(const ConvArgs* args, int n, int variant) {
+    if (n < 2 || n > 8 || variant < 0 || variant >= kNumSbVariants) return false;
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!conv_sb_supported(args[i], variant)) return false;
+        SbGeom g;
+        sb_geometry(args[i], kSbVariants[variant], g);
+        tiles += (long)g.mt * g.nt;
+    }
+    return tiles <= 16384;
+}
+
+// fills host_buf (conv_sb_group_bytes(n)) with the problem table of the launch; returns the number of tiles
+int conv_sb_group_build(const ConvArgs* args, int n, int variant, void* host_buf) {
+    if (!conv_sb_group_supported(args, n, variant)) fail(RMR_ERR_LOGIC, "conv_sb: group not supported by variant %d", variant);
+    SbProblem* p = (SbProblem*)host_buf;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        p[i] = SbProblem{};
+        p[i].a = args[i];
+        sb_geometry(args[i], kSbVariants[variant], p[i].g);
+        p[i].tile0 = tiles;
+        tiles += p[i].g.mt * p[i].g.nt;
+        if (args[i].in_cs % 8 || args[i].in_co % 8 || args[i].out_cs % 4 || args[i].out_co % 4) fail(RMR_ERR_LOGIC, "conv_sb: misaligned view");
+    }
+    return tiles;
+}
+
+void launch_conv_sb_group(DeviceCtx& ctx, hipStream_t stream, const ConvArgs* args, int n, const void* dev_probs, int variant) {
+    if (!conv_sb_group_supported(args, n, variant)) fail(RMR_ERR_LOGIC, "conv_sb: group not supported by variant %d", variant);
+    const SbVariant& v = kSbVariants[variant];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const SbVariant& d : kSbVariants) (void)hipFuncSetAttribute((const void*)d.group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    int lds = 0, tiles = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        SbGeom g;
+        lds = std::max(lds, sb_geometry(args[i], v, g));
+        tiles += g.mt * g.nt;
+        const ConvArgs& a = args[i];
+        flops += a.flops > 0 ? a.flops : 2.0 * a.M * (double)a.Cout_pad * a.K;
+        bytes += 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.M * a.Cout_pad + (double)a.Cout_pad * a.K);
+    }
+    static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
+    static std::mutex name_mu;
+    static std::map<std::string, std::string> names;
+    const char* pname = "conv_igemm_f16";
+    if (per_layer && ctx.prof.on) {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "conv n%d group of %d (M%d N%d K%d k%d ...) b%d", args[0].N, n, args[0].M, args[0].Cout_pad, args[0].K, args[0].KH, variant);
+        std::lock_guard<std::mutex> lk(name_mu);
+        pname = names.emplace(buf, buf).first->second.c_str();
+    }
+    ProfScope ps(ctx.prof, stream, pname, flops, bytes);
+    v.group_kernel<<<tiles, v.threads, lds, stream>>>((const SbProblem*)dev_probs, n, tiles);
     RMR_HIP(hipGetLastError());
 }
 

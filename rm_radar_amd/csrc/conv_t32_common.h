@@ -262,6 +262,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, floatx16 (&acc)[MREP
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int n = n0 + (wn * NREP + j) * 32 + gq * 8 + cq;
+                if (n >= a.Cout_pad) continue;   // conv_sb: a 32-channel tile over a 16-channel view (the class logits)
                 const float4 b = *(const float4*)(a.bias + n);
                 float v[4] = {acc[i][j][gq * 4 + 0] + b.x, acc[i][j][gq * 4 + 1] + b.y, acc[i][j][gq * 4 + 2] + b.z,
                               acc[i][j][gq * 4 + 3] + b.w};

@@ -104,6 +104,10 @@ class Yolov8 {
         // tuned choice of 340.. for this op runs both in one launch (conv_wsf: the hidden tensor stays in LDS); the second op
         // then carries the choice kFusedAway and launches nothing
         int fuse_with = -1;
+        // a run of consecutive, mutually independent convolutions (the Detect head: the same depth of its branches): index into
+        // groups_, -1 = none.  A tuned choice of kSbGroupBase + variant on the group's FIRST op runs all of them in one conv_sb
+        // launch; the others then carry kGroupedAway and launch nothing
+        int group = -1;
         // OP_HEAD
         View box, cls;
         int head_stride = 0, a_off = 0;
@@ -143,6 +147,12 @@ class Yolov8 {
     int tune_conv(hipStream_t s, const ConvArgs& a, float* best_ms_out = nullptr);
     ConvArgs fused_args(int op_index, int n, size_t img0);   // ConvArgs of a fused bottleneck (op_index = its first convolution)
     static constexpr int kFusedAway = 399;
+    std::vector<std::vector<int>> groups_;                                   // op indices, in op order
+    std::map<std::pair<int, int>, DevBuf<unsigned char>> group_tables_;      // (first op of a group, images) -> the launch's problem table
+    void find_groups();
+    std::vector<ConvArgs> group_args(int g, int n);
+    void ensure_group_table(int g, int n, int variant);
+    void tune_group(hipStream_t s, int g, int n, size_t img0);
     std::map<std::pair<int, int>, float> tuned_ms_;   // the tuner's time of the first convolution of a fusable pair
 
     DeviceCtx& ctx_;

@@ -340,6 +340,119 @@ View Yolov8::c2f(const WeightPack& p, const std::string& name, const View& x, in
     return out;
 }
 
+// Runs of consecutive convolutions that do not depend on one another (before the arenas are compacted: a buffer is still its
+// own region, two views overlap when they name the same region and their channel ranges meet)
+void Yolov8::find_groups() {
+    const auto meet = [](const View& x, bool xf, const View& y, bool yf) {
+        return (x.c || x.cs) && (y.c || y.cs) && xf == yf && x.off == y.off && x.co < y.co + y.c && y.co < x.co + x.c;
+    };
+    const auto plain = [&](const Op& o) {
+        return o.kind == OP_CONV && !o.fp8 && !o.q_out && !o.in_is_input && o.fuse_with < 0 && !o.in_slab_c && !o.out_slab_c && !o.pre.c;
+    };
+    const auto independent = [&](const Op& x, const Op& y) {   // x before y
+        if (meet(x.out, x.out_f32, y.in, false) || meet(x.out, x.out_f32, y.res, false)) return false;   // y reads what x writes
+        if (meet(y.out, y.out_f32, x.in, false) || meet(y.out, y.out_f32, x.res, false)) return false;   // y overwrites what x reads
+        return !meet(x.out, x.out_f32, y.out, y.out_f32);
+    };
+    for (size_t i = 0; i < ops_.size();) {
+        if (!plain(ops_[i])) {
+            ++i;
+            continue;
+        }
+        size_t j = i + 1;
+        for (; j < ops_.size() && j - i < 8 && plain(ops_[j]); ++j) {
+            // one launch = one kernel form: 3x3 / stride-1 layers with one another (the halo form), everything else likewise
+            bool ok = convs_[ops_[j].conv].k == convs_[ops_[i].conv].k && ops_[j].stride == ops_[i].stride;
+            for (size_t k = i; k < j && ok; ++k) ok = independent(ops_[k], ops_[j]);
+            // a fusable bottleneck's second convolution never joins (its partner may have taken it along)
+            if (!ok || (j > 0 && ops_[j - 1].fuse_with == (int)j)) break;
+        }
+        if (j - i >= 2) {
+            std::vector<int> g;
+            for (size_t k = i; k < j; ++k) {
+                ops_[k].group = (int)groups_.size();
+                g.push_back((int)k);
+            }
+            groups_.push_back(g);
+        }
+        i = j;
+    }
+}
+
+std::vector<ConvArgs> Yolov8::group_args(int g, int n) {
+    std::vector<ConvArgs> v;
+    for (int op : groups_[g]) v.push_back(conv_args(op, n, 0));
+    return v;
+}
+
+// the problem table of a grouped launch, in device memory for as long as the detector lives (captured graphs name it)
+void Yolov8::ensure_group_table(int g, int n, int variant) {
+    const std::vector<ConvArgs> args = group_args(g, n);
+    std::vector<unsigned char> host(conv_sb_group_bytes((int)args.size()));
+    conv_sb_group_build(args.data(), (int)args.size(), variant, host.data());
+    DevBuf<unsigned char>& d = group_tables_[{groups_[g].front(), n}];
+    d.alloc(host.size());
+    RMR_HIP(hipMemcpy(d.p, host.data(), host.size(), hipMemcpyHostToDevice));
+}
+
+// First visit of a group at n images: every member is tuned on its own (and has run), then the grouped launch of every conv_sb
+// variant that takes all of them is timed against the sum of the members' launches
+void Yolov8::tune_group(hipStream_t s, int g, int n, size_t img0) {
+    const std::vector<int>& ops = groups_[g];
+    float sum_ms = 0.f;
+    for (int op : ops) {
+        if (tuned_.count({op, n})) return;   // a partly tuned group (an older cache): leave it as it is
+    }
+    for (int op : ops) {
+        float ms = 0.f;
+        tuned_[{op, n}] = tune_conv(s, conv_args(op, n, img0), &ms);
+        sum_ms += ms;
+    }
+    tuned_dirty_ = true;
+    static const bool off = std::getenv("RMR_GROUPS") && std::atoi(std::getenv("RMR_GROUPS")) == 0;   // RMR_GROUPS=0: never group
+    if (off) return;
+    const std::vector<ConvArgs> args = group_args(g, n);
+    hipEvent_t e0, e1;
+    RMR_HIP(hipEventCreate(&e0));
+    RMR_HIP(hipEventCreate(&e1));
+    const int prof_was_on = ctx_.prof.on;
+    ctx_.prof.on = 0;
+    float best_ms = 1e30f;
+    int best_v = -1;
+    DevBuf<unsigned char> table;
+    std::vector<unsigned char> host(conv_sb_group_bytes((int)args.size()));
+    table.alloc(host.size());
+    for (int v = 0; v < conv_sb_num_variants(); ++v) {
+        if (!conv_sb_group_supported(args.data(), (int)args.size(), v)) continue;
+        conv_sb_group_build(args.data(), (int)args.size(), v, host.data());
+        RMR_HIP(hipMemcpy(table.p, host.data(), host.size(), hipMemcpyHostToDevice));
+        float v_ms = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            RMR_HIP(hipEventRecord(e0, s));
+            launch_conv_sb_group(ctx_, s, args.data(), (int)args.size(), table.p, v);
+            RMR_HIP(hipEventRecord(e1, s));
+            RMR_HIP(hipEventSynchronize(e1));
+            float t = 0;
+            RMR_HIP(hipEventElapsedTime(&t, e0, e1));
+            if (rep > 0) v_ms = std::min(v_ms, t);
+        }
+        if (std::getenv("RMR_TUNE_VERBOSE")) fprintf(stderr, " g%d:%.1f", v, v_ms * 1e3f);
+        if (v_ms < best_ms) best_ms = v_ms, best_v = v;
+    }
+    ctx_.prof.on = prof_was_on;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    static const bool verbose = std::getenv("RMR_TUNE_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "group of %zu layers from %d at %d images: %.1f us one by one, conv_sb variant %d %.1f us in one launch -> %s\n", ops.size(), ops.front(), n,
+                sum_ms * 1e3f, best_v, best_ms * 1e3f, best_v >= 0 && best_ms < 0.97f * sum_ms ? "grouped" : "one by one");
+    if (best_v >= 0 && best_ms < 0.97f * sum_ms) {
+        ensure_group_table(g, n, best_v);
+        tuned_[{ops.front(), n}] = kSbGroupBase + best_v;
+        for (size_t k = 1; k < ops.size(); ++k) tuned_[{ops[k], n}] = kGroupedAway;
+    }
+}
+
 void Yolov8::compact_arenas() {
     // merge the allocations of a group into one block (their relative placement is part of the plan)
     struct Block {
@@ -362,12 +475,14 @@ void Yolov8::compact_arenas() {
             if (b.arena == arena && off >= b.off && off < b.off + b.size) return &b;
         return nullptr;
     };
-    const auto touch = [&](int arena, size_t off, int i) {
-        if (Block* b = block_of(arena, off)) b->first = std::min(b->first, i), b->last = std::max(b->last, i);
-    };
     // lifetimes: the ops run in order on one stream
-    for (int i = 0; i < (int)ops_.size(); ++i) {
-        const Op& op = ops_[i];
+    for (int i0 = 0; i0 < (int)ops_.size(); ++i0) {
+        const Op& op = ops_[i0];
+        // the ops of a group may run in one launch: what any of them touches lives over the whole group
+        const int i = i0, i_hi = op.group >= 0 ? groups_[op.group].back() : i0, i_lo = op.group >= 0 ? groups_[op.group].front() : i0;
+        const auto touch = [&](int arena, size_t off, int) {
+            if (Block* b = block_of(arena, off)) b->first = std::min(b->first, i_lo), b->last = std::max(b->last, i_hi);
+        };
         const auto view = [&](const View& v, bool f32) {
             if (v.c || v.cs) touch(f32 ? 1 : 0, v.off, i);
         };
@@ -586,23 +701,38 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     int a_off = 0;
     const int cls_pad = (nc_ + 15) / 16 * 16;
     std::vector<Op> head_ops;
+    // depth-major: the first convolutions of the three scales, then the six second ones, then the six third ones -- the
+    // convolutions of one depth are independent of each other, consecutive in the op list, and can leave in ONE launch
+    // (find_groups; a batch-1 layer is mostly fixed cost: 15 launches become 3)
+    struct HeadScale {
+        View h1, hb, hc, box, cls;
+        int c2d, c3d;
+    } hs[3];
     for (int i = 0; i < 3; ++i) {
         const View& f = feats[i];
         const std::string b = "model.22.cv2." + std::to_string(i), c = "model.22.cv3." + std::to_string(i);
-        const int c2d = (int)p.get(b + ".0.conv.weight").dims[0];
-        const int c3d = (int)p.get(c + ".0.conv.weight").dims[0];
-        View h1 = alloc(f.h, f.w, c2d + c3d);
-        conv(add_fused_head_weights(p, b + ".0.conv", c + ".0.conv"), f, h1, 1, 1);
-        View hb = alloc(f.h, f.w, c2d), hc = alloc(f.h, f.w, c3d);
-        conv(add_conv_weights(p, b + ".1.conv", 0), slice(h1, 0, c2d), hb, 1, 1);
-        conv(add_conv_weights(p, c + ".1.conv", 0), slice(h1, c2d, c3d), hc, 1, 1);
-        View box = alloc(f.h, f.w, 64, true), cls = alloc(f.h, f.w, cls_pad, true);
-        conv(add_conv_weights(p, b + ".2", 0), hb, box, 1, 0, nullptr, true);
-        conv(add_conv_weights(p, c + ".2", 0), hc, cls, 1, 0, nullptr, true);
+        hs[i].c2d = (int)p.get(b + ".0.conv.weight").dims[0];
+        hs[i].c3d = (int)p.get(c + ".0.conv.weight").dims[0];
+        hs[i].h1 = alloc(f.h, f.w, hs[i].c2d + hs[i].c3d);
+        conv(add_fused_head_weights(p, b + ".0.conv", c + ".0.conv"), f, hs[i].h1, 1, 1);
+    }
+    for (int i = 0; i < 3; ++i) {
+        const View& f = feats[i];
+        const std::string b = "model.22.cv2." + std::to_string(i), c = "model.22.cv3." + std::to_string(i);
+        hs[i].hb = alloc(f.h, f.w, hs[i].c2d), hs[i].hc = alloc(f.h, f.w, hs[i].c3d);
+        conv(add_conv_weights(p, b + ".1.conv", 0), slice(hs[i].h1, 0, hs[i].c2d), hs[i].hb, 1, 1);
+        conv(add_conv_weights(p, c + ".1.conv", 0), slice(hs[i].h1, hs[i].c2d, hs[i].c3d), hs[i].hc, 1, 1);
+    }
+    for (int i = 0; i < 3; ++i) {
+        const View& f = feats[i];
+        const std::string b = "model.22.cv2." + std::to_string(i), c = "model.22.cv3." + std::to_string(i);
+        hs[i].box = alloc(f.h, f.w, 64, true), hs[i].cls = alloc(f.h, f.w, cls_pad, true);
+        conv(add_conv_weights(p, b + ".2", 0), hs[i].hb, hs[i].box, 1, 0, nullptr, true);
+        conv(add_conv_weights(p, c + ".2", 0), hs[i].hc, hs[i].cls, 1, 0, nullptr, true);
         Op op{};
         op.kind = OP_HEAD;
-        op.box = box;
-        op.cls = cls;
+        op.box = hs[i].box;
+        op.cls = hs[i].cls;
         op.head_stride = strides[i];
         op.a_off = a_off;
         op.in = f;
@@ -672,6 +802,7 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
             if (only) a.fuse_with = (int)i + 1;
         }
     }
+    find_groups();
     if (arena_reuse_) compact_arenas();
     // Images per launch: every activation view (pixels x its buffer's channel pitch, plus the span of its
     // slabs) must stay below the 32-bit offset range of the kernels' buffer resources.  256 images of a
@@ -935,7 +1066,7 @@ unsigned long long Yolov8::plan_signature() const {
     unsigned long long h = 1469598103934665603ull;
     const auto mix = [&](long long v) { h = (h ^ (unsigned long long)v) * 1099511628211ull; };
     for (const Op& op : ops_) {
-        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs), mix(op.fp8), mix(op.q_pitch), mix(op.q_out), mix(op.q_only);
+        mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs), mix(op.fp8), mix(op.q_pitch), mix(op.q_out), mix(op.q_only), mix(op.group);
         if (op.kind == OP_CONV) mix(convs_[op.conv].K), mix(convs_[op.conv].cout_pad);
     }
     return h;
@@ -1005,7 +1136,15 @@ void Yolov8::load_tuning() {
     int op, n, choice;
     while (f >> op >> n >> choice) {
         if (op < 0 || op >= (int)ops_.size() || ops_[op].kind != OP_CONV || n < 1 || n > chunk_) continue;
-        if (choice == kFusedAway) {
+        if (choice == kGroupedAway) {
+            if (ops_[op].group >= 0 && groups_[ops_[op].group].front() != op) tuned_[{op, n}] = choice;
+        } else if (choice >= kSbGroupBase) {
+            const int g = ops_[op].group;
+            if (g >= 0 && groups_[g].front() == op) {
+                const std::vector<ConvArgs> args = group_args(g, n);
+                if (conv_sb_group_supported(args.data(), (int)args.size(), choice - kSbGroupBase)) tuned_[{op, n}] = choice;
+            }
+        } else if (choice == kFusedAway) {
             if (op > 0 && ops_[op - 1].kind == OP_CONV && ops_[op - 1].fuse_with == op) tuned_[{op, n}] = choice;
         } else if (choice >= 340 && choice < kFusedAway) {
             if (ops_[op].fuse_with >= 0 && conv_wsf_supported(fused_args(op, n, 0), choice - 340)) tuned_[{op, n}] = choice;
@@ -1023,6 +1162,22 @@ void Yolov8::load_tuning() {
             drop = f == tuned_.end() || f->second < 340 || f->second >= kFusedAway;
         }
         it = drop ? tuned_.erase(it) : std::next(it);
+    }
+    // a grouped launch is an entry on the group's first layer and "done by the group's launch" on all the others: anything
+    // less (a hand-edited or truncated file) falls back to tuning the whole group again
+    for (size_t g = 0; g < groups_.size(); ++g) {
+        std::map<int, int> per_n;   // images -> 0 none, 1 consistent group, -1 broken
+        for (const auto& kv : tuned_)
+            if (ops_[kv.first.first].group == (int)g && (kv.second >= kSbGroupBase || kv.second == kGroupedAway)) per_n[kv.first.second] = 0;
+        for (auto& pn : per_n) {
+            const int n2 = pn.first;
+            bool ok = tuned_.count({groups_[g].front(), n2}) && tuned_[{groups_[g].front(), n2}] >= kSbGroupBase;
+            for (size_t k = 1; k < groups_[g].size() && ok; ++k) ok = tuned_.count({groups_[g][k], n2}) && tuned_[{groups_[g][k], n2}] == kGroupedAway;
+            if (ok)
+                ensure_group_table((int)g, n2, tuned_[{groups_[g].front(), n2}] - kSbGroupBase);
+            else
+                for (int op2 : groups_[g]) tuned_.erase({op2, n2});
+        }
     }
     for (auto& kv : tuned_)
         if (kv.second >= 340 && kv.second < kFusedAway) {
@@ -1170,6 +1325,19 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
                     launch_conv_auto(ctx_, s, a);
                 }
                 break;
+            }
+            if (op.group >= 0) {
+                const std::vector<int>& members = groups_[op.group];
+                if (!tuned_.count({op_index, n}) && !pinned_ && members.front() == op_index) tune_group(s, op.group, n, img0);
+                const auto gi = tuned_.find({op_index, n});
+                if (gi != tuned_.end() && gi->second == kGroupedAway) break;   // done by the launch of the group's first layer
+                if (gi != tuned_.end() && gi->second >= kSbGroupBase) {
+                    const auto tb = group_tables_.find({op_index, n});
+                    if (tb == group_tables_.end()) fail(RMR_ERR_LOGIC, "grouped launch of layer %d at %d images has no problem table", op_index, n);
+                    const std::vector<ConvArgs> args = group_args(op.group, n);
+                    launch_conv_sb_group(ctx_, s, args.data(), (int)args.size(), tb->second.p, gi->second - kSbGroupBase);
+                    break;
+                }
             }
             auto key = std::make_pair(op_index, n);
             auto it = tuned_.find(key);
