@@ -267,16 +267,19 @@ def cpu_baseline(args, packs, images, clouds, rects):
             list(ex.map(work, range(workers)))
         return time.perf_counter() - t0
 
-    # no warm-up frame: a frame is tens of seconds of CPU work at these thread counts, the pools' spin-up is not
+    # one UNTIMED frame per worker first: oneDNN's primitive creation / JIT for the two shapes and the spin-up of each worker's
+    # intra-op team would otherwise sit inside a one-frame sample and bias the CPU figure downward
     per_worker = max(1, args.cpu_frames)
-    dt = run(per_worker, 0)
+    warm_dt = run(1, 0)
+    dt = run(per_worker, workers)
     torch.set_num_threads(prev_threads)
     n = workers * per_worker
     return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "workers": workers, "threads_per_worker": threads,
             "sample": f"{n} frame(s) of the same workload ({workers} workers x {per_worker} frame(s), {threads} torch intra-op "
                       f"threads each; per frame 1 car + {args.crops} armor YOLOv8m forwards in PyTorch-CPU fp32, C oracle "
-                      f"pre/post/locate on the worker's own Locator stream), {dt:.1f} s"}
+                      f"pre/post/locate on the worker's own Locator stream), {dt:.1f} s, after one untimed warm-up frame per worker "
+                      f"({warm_dt:.1f} s)"}
 
 
 PLAN_DIR = os.path.join(ROOT, "profiles", "plans")

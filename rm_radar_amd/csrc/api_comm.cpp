@@ -82,6 +82,7 @@ struct rmr_comm {
     // after a crash, a caller-supplied path -- can never read a record file an earlier one left behind.  The epoch is a
     // COLLECTIVE value (round 4; before, every rank derived it from its own surviving markers and two ranks could
     // disagree after a clean close or a crash): rank 0 picks 1 + the highest epoch of ANY file still in the directory
+    // (after a clean close has swept the directory that is epoch 0 again: safe, nothing of the earlier epoch 0 is left to read)
     // and hands it to every other rank in a token handshake (agree_on_epoch), which makes creation a collective call
     // like ncclCommInitRank.
     std::string dir;
@@ -121,8 +122,8 @@ struct rmr_comm {
     // (a welcome left by an earlier communicator, or one answering a hello a crashed process left, has another token and
     // is ignored).  Rank 0 picks the epoch, then keeps answering whatever token each hello currently holds until that
     // rank's session marker of the new epoch appears (the caller writes it right after this returns).
-    static long long agree_on_epoch(const std::string& dir, int rank, int world) {
-        const auto t0 = std::chrono::steady_clock::now();
+    // t0: when rmr_comm_create was entered -- ONE deadline of 120 s covers the handshake and rank 0's wait for the session markers
+    static long long agree_on_epoch(const std::string& dir, int rank, int world, std::chrono::steady_clock::time_point t0) {
         const auto late = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120); };
         if (rank != 0) {
             std::random_device rd;
@@ -246,9 +247,11 @@ rmr_status rmr_comm_create(int transport, int device, int rank, int world, const
             struct stat st;
             if (c->dir.empty() || stat(c->dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode))
                 fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: '%s' is not a directory", c->dir.c_str());
-            c->epoch = rmr_comm::agree_on_epoch(c->dir, rank, world);
+            const auto t_enter = std::chrono::steady_clock::now();
+            c->epoch = rmr_comm::agree_on_epoch(c->dir, rank, world, t_enter);
             rmr_comm::touch(c->file("session", -1, rank));   // for ranks != 0 this is also the ack rank 0 waits for
-            if (rank == 0 && !c->wait_all("session", 120.0))
+            const double left = 120.0 - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
+            if (rank == 0 && !c->wait_all("session", std::max(0.0, left)))
                 fail(RMR_ERR_RUNTIME, "rmr_comm_create: not every rank joined '%s' within 120 s", c->dir.c_str());
             c->joined = true;
         } else {

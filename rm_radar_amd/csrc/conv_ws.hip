@@ -1033,6 +1033,17 @@ void launch_conv_wsf(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant
     if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8) fail(RMR_ERR_LOGIC, "conv_wsf: misaligned view");
     if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull) fail(RMR_ERR_LOGIC, "conv_wsf: input view size not set or larger than 3.75 GiB");
     if (!a.out32 && (double)a.M * a.out_cs * 2 >= 4.0e9) fail(RMR_ERR_LOGIC, "conv_wsf: output view of 4 GB or more (32-bit store offsets)");
+    // The input is read twice -- as the first convolution's operand (with halo rows that other workgroups own) and as the
+    // shortcut -- while the output is written: an output view on top of the input view (same bytes, meeting channel ranges)
+    // would race across the strips' halos.  (The two-launch path tolerates out == res; this one does not.)
+    if (!a.out32) {
+        const char *ib = (const char*)a.in, *ie = ib + (size_t)a.N * a.H * a.W * a.in_cs * 2;
+        const char *ob = (const char*)a.out, *oe = ob + (size_t)a.M * a.out_cs * 2;
+        const bool bytes_meet = ob < ie && ib < oe;
+        const bool same_pitch = a.in_cs == a.out_cs && ((ob - ib) % ((long)a.in_cs * 2)) == 0;
+        const bool channels_meet = !same_pitch || (a.out_co < a.in_co + a.Cin && a.in_co < a.out_co + a.Cout_pad);
+        if (bytes_meet && channels_meet) fail(RMR_ERR_LOGIC, "conv_wsf: the output view overlaps the input view (the fused bottleneck cannot run in place)");
+    }
     static std::once_flag once;
     std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)conv_wsf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1079,6 +1090,8 @@ void launch_conv_ws(DeviceCtx& ctx, hipStream_t stream, ConvArgs a, int variant)
         fail(RMR_ERR_LOGIC, "conv_ws: misaligned view");
     if (a.in_bytes == 0 || a.in_bytes > 0xf0000000ull) fail(RMR_ERR_LOGIC, "conv_ws: input view size not set or larger than 3.75 GiB");
     if (!a.out32 && (double)a.M * a.out_cs * 2 >= 4.0e9) fail(RMR_ERR_LOGIC, "conv_ws: output view of 4 GB or more (32-bit store offsets)");
+    // the shortcut is addressed with 32-bit byte offsets as well, and may be a slice of a WIDER buffer than the output
+    if (a.res && (double)a.M * a.res_cs * 2 >= 4.0e9) fail(RMR_ERR_LOGIC, "conv_ws: shortcut view of 4 GB or more (32-bit load offsets)");
     using Kern = void (*)(const ConvArgs, int);
 #define WS_KERNELS(NJ)                                                                                   \
     {conv_ws_kernel<false, false, false, NJ>, conv_ws_kernel<false, false, true, NJ>,                    \

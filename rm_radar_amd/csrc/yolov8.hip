@@ -775,9 +775,8 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     // and adds the first's input, and nobody else reads the hidden tensor.  The pairs are always found (a plan may name the
     // fused kernel for them); whether the TUNER tries the fused launch is RMR_FUSE_WS (default off, see run_op).
     {
-        const bool on = true;
         const auto same = [](const View& x, const View& y) { return x.off == y.off && x.co == y.co && x.c == y.c && x.cs == y.cs && x.h == y.h && x.w == y.w; };
-        for (size_t i = 0; on && i + 1 < ops_.size(); ++i) {
+        for (size_t i = 0; i + 1 < ops_.size(); ++i) {
             Op& a = ops_[i];
             const Op& b = ops_[i + 1];
             if (a.kind != OP_CONV || b.kind != OP_CONV || a.fp8 || b.fp8 || a.out_f32 || b.out_f32 || a.in_is_input) continue;
@@ -1341,6 +1340,11 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
             }
             auto key = std::make_pair(op_index, n);
             auto it = tuned_.find(key);
+            if (it == tuned_.end() && conv_stem_supported(a)) {
+                // the first layer has one kernel (tune_conv says so without timing anything): a pinned plan need not name it, so the
+                // separate-letterbox paths (RMR_FUSE_LB=0) run under the committed plans too
+                it = tuned_.emplace(key, 500).first;
+            }
             if (it == tuned_.end()) {
                 if (pinned_)
                     fail(RMR_ERR_RUNTIME, "pinned plan '%s' has no kernel for layer %d at %d images (RMR_PLAN names a file written for this pack, input size and batch sizes)",

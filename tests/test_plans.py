@@ -40,8 +40,15 @@ def test_committed_plan_is_of_this_library_version_and_consistent(name):
     for (op, n), c in by.items():
         if c == 399:                           # "done by the layer before": only behind a fused bottleneck (340..)
             assert 340 <= by.get((op - 1, n), -1) < 399, (op, n)
-        if 340 <= c < 399:
+        if 340 <= c < 398:
             assert by.get((op + 1, n)) == 399, (op, n)
+        if c == 398:                           # "done by the group's launch": behind a grouped launch (200000..) a few layers back
+            k = op - 1
+            while by.get((k, n)) == 398:
+                k -= 1
+            assert by.get((k, n), -1) >= 200000 and op - k < 8, (op, n)
+        if c >= 200000:                        # a grouped launch carries at least one more layer
+            assert by.get((op + 1, n)) == 398, (op, n)
 
 
 def test_make_plan_parses_the_tuners_log(tmp_path):

@@ -132,7 +132,9 @@ def plan_for(which, nc, n, dtype, work):
     FUSED_AWAY = 399   # the second convolution of a fused bottleneck (conv_wsf, choice 340.. on the layer before): no launch
     choices = [chosen for chosen, _, _ in tuned]          # the two-launch choices, whatever the library then decided about fusing
     if n < 16:
-        return header, ops, choices, None
+        # small batches: the library's own result, grouped launches included (kSbGroupBase + variant on a group's first layer, 398 =
+        # "done by the group's launch" on the others: tune records exist for every member, the file says what was decided)
+        return header, ops, [c for _, c in ops], None
     index_of = {op: k for k, (op, _) in enumerate(ops)}
     fusions = {index_of[a]: (index_of[b], v) for a, (b, v) in parse_fusions(log).items()}
     alts = []
