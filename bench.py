@@ -356,6 +356,11 @@ class Ranks:
                 except Exception as e:  # noqa: BLE001
                     self.comm = None
                     self.gather_via += f" [C-ABI communicator unavailable: {type(e).__name__}: {e}]"
+                    # the first real N > 1 run must be diagnosable from its log: the library's message carries the IPC mode and
+                    # RCCL's switches; the launcher's view of the same environment goes beside it
+                    env_keys = ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "LOCAL_RANK")
+                    print(f"[bench] rank {self.rank}: C-ABI communicator ({transport}) unavailable, falling back to torch.distributed: "
+                          f"{type(e).__name__}: {e} | " + " ".join(f"{k}={os.environ.get(k, '(unset)')}" for k in env_keys), file=sys.stderr, flush=True)
                 # every rank must take the same road from here on: one rank gathering through the C-ABI communicator while
                 # another fell back to torch.distributed would hang both
                 ok = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int32, device=self.dev)

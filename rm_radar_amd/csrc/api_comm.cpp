@@ -66,6 +66,19 @@ Rccl& rccl() {
     return r;
 }
 
+// What a failed communicator set-up needs to be diagnosed from a log: the IPC mode (this driver only supports dmabuf IPC:
+// HSA_ENABLE_IPC_MODE_LEGACY=0), RCCL's own switches, who we are
+std::string comm_env_report(int transport, int rank, int world, int device) {
+    const auto ev = [](const char* k) {
+        const char* v = std::getenv(k);
+        return std::string(k) + "=" + (v ? v : "(unset)");
+    };
+    return "transport " + std::string(transport == RMR_TRANSPORT_RCCL ? "RCCL" : "FILE") + ", rank " + std::to_string(rank) + " of " + std::to_string(world) +
+           ", device " + std::to_string(device) + "; " + ev("HSA_ENABLE_IPC_MODE_LEGACY") + " " + ev("NCCL_DEBUG") + " " + ev("NCCL_SOCKET_IFNAME") + " " +
+           ev("NCCL_IB_DISABLE") + " " + ev("HIP_VISIBLE_DEVICES") + " " + ev("ROCR_VISIBLE_DEVICES") +
+           " (set NCCL_DEBUG=INFO for RCCL's own account of the failure)";
+}
+
 void nccl_check(ncclResult_t e, const char* what) {
     if (e != ncclSuccess) fail(RMR_ERR_DEVICE, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(e) : "RCCL error");
 }
@@ -235,13 +248,22 @@ rmr_status rmr_comm_create(int transport, int device, int rank, int world, const
         if (!out || !id || world < 1 || rank < 0 || rank >= world) fail(RMR_ERR_INVALID_ARGUMENT, "rmr_comm_create: bad arguments");
         auto c = std::make_unique<rmr_comm>();
         c->transport = transport, c->rank = rank, c->world = world, c->device = device;
+        // RMR_COMM_INJECT_FAILURE=1 (tests): fail where ncclCommInitRank would, with the same account of the environment, so that
+        // the first multi-GPU run's log can be checked to carry what a diagnosis needs before such a run exists
+        if (const char* inj = std::getenv("RMR_COMM_INJECT_FAILURE"))
+            if (std::atoi(inj) != 0)
+                fail(RMR_ERR_DEVICE, "communicator set-up failed (injected): %s [%s]", transport == RMR_TRANSPORT_RCCL ? "ncclCommInitRank" : "file handshake",
+                     comm_env_report(transport, rank, world, device).c_str());
         if (transport == RMR_TRANSPORT_RCCL) {
             DeviceCtx& ctx = device_ctx(device);  // fails loudly without a usable GPU
             ctx.use();
             ncclUniqueId u;
             std::memcpy(&u, id, sizeof(u));
             RMR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-            nccl_check(rccl().CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");
+            const ncclResult_t ie = rccl().CommInitRank(&c->comm, world, u, rank);
+            if (ie != ncclSuccess)
+                fail(RMR_ERR_DEVICE, "ncclCommInitRank failed: %s [%s]", rccl().GetErrorString ? rccl().GetErrorString(ie) : "RCCL error",
+                     comm_env_report(transport, rank, world, device).c_str());
         } else if (transport == RMR_TRANSPORT_FILE) {
             c->dir.assign(id, strnlen(id, RMR_COMM_ID_BYTES));
             struct stat st;

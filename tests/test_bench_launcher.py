@@ -47,3 +47,15 @@ def test_gpus_2_without_two_gpus_is_an_error():
 def test_world_size_must_match_gpus():
     p = _run(["--gpus", "2", "--stub-step"], env={"RANK": "0", "WORLD_SIZE": "1"})
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def test_a_failed_communicator_is_diagnosable_from_the_log():
+    # a failure of the C-ABI communicator's set-up (on a GPU node: ncclCommInitRank) must not end the run -- every rank falls
+    # back to torch.distributed together -- and must leave in the log what a diagnosis needs: the IPC mode, RCCL's switches
+    p = _run(["--gpus", "2", "--stub-step", "--steps", "2", "--warmup", "0", "--batch", "4"], env={"RMR_COMM_INJECT_FAILURE": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == [0, 1]
+    assert "torch.distributed" in r["gather"] and "unavailable" in r["gather"]
+    for needle in ("falling back to torch.distributed", "HSA_ENABLE_IPC_MODE_LEGACY=", "NCCL_DEBUG=", "rank 0 of 2", "rank 1 of 2"):
+        assert needle in p.stderr, (needle, p.stderr[-1500:])
