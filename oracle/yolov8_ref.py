@@ -92,8 +92,13 @@ def _check_against_ultralytics(tensors, scale, nc):
 
 
 class YoloV8Ref:
-    def __init__(self, tensors, meta, emulate_f16=False, fp8=False):
+    def __init__(self, tensors, meta, emulate_f16=False, fp8=False, jitter=0.0, jitter_seed=0):
         self.meta = meta
+        # jitter > 0: every convolution's f32 result is multiplied by 1 + jitter * u, u uniform in [-1, 1) -- ANOTHER exact
+        # implementation of the same plan (another f32 summation order moves a result by a few 2^-24 of its value): how far
+        # two such implementations drift apart is the reproducibility floor of a plan (tools/fp8_parity_study.py)
+        self.jitter = float(jitter)
+        self._jg = torch.Generator().manual_seed(int(jitter_seed))
         self.f16 = emulate_f16 or fp8
         self.fp8 = fp8
         import os
@@ -117,6 +122,8 @@ class YoloV8Ref:
             scale = (w.abs().flatten(1).max(1).values / 448.0).clamp_min(1e-30).view(-1, 1, 1, 1)
             w = _e4m3(w / scale) * scale
         y = F.conv2d(x, w, b, stride=s, padding=k // 2)
+        if self.jitter:
+            y = y * (1.0 + self.jitter * (2.0 * torch.rand(y.shape, generator=self._jg) - 1.0))
         if act:
             y = y * torch.sigmoid(y)
         if residual is not None:
@@ -225,7 +232,7 @@ class YoloV8Ref:
         return self.decode_head(box, cls, shapes).numpy()
 
 
-def load(path, emulate_f16=False, fp8=False):
+def load(path, emulate_f16=False, fp8=False, jitter=0.0, jitter_seed=0):
     from rm_radar_amd import weights as W
     tensors, meta = W.load_pack(path)
-    return YoloV8Ref(tensors, meta, emulate_f16, fp8)
+    return YoloV8Ref(tensors, meta, emulate_f16, fp8, jitter, jitter_seed)

@@ -518,9 +518,59 @@ def test_fp8_plan_at_its_own_batch_of_256(rmr, packs, images):
         assert np.abs(g[:4] - w16[:4]).mean() <= 4.5 and np.abs(g[4:] - w16[4:]).mean() <= 2e-3
         worst = max(worst, impl_b / quant_b)
     print(f"fp8 plan at 256 images: worst slot is {worst:.2f} of the quantisation distance from its oracle")
+    # the absolute bar (tools/fp8_parity_study.py): ANOTHER exact implementation of the same plan -- the oracle with every
+    # convolution result moved by 2^-22 of its value -- is this far from the oracle; the engine may not be further
+    jit = R.load(packs[1], fp8=True, jitter=2.0 ** -22, jitter_seed=1).forward(blobs)
+    floor_b, floor_s = np.abs(jit[:, :4] - want8[:, :4]).mean(), np.abs(jit[:, 4:] - want8[:, 4:]).mean()
+    eng_b, eng_s = np.abs(got[:3, :4] - want8[:, :4]).mean(), np.abs(got[:3, 4:] - want8[:, 4:]).mean()
+    print(f"fp8 plan at 256 images vs its oracle: box {eng_b:.3f} px score {eng_s:.5f}; two exact implementations: {floor_b:.3f} px {floor_s:.5f}")
+    assert eng_b <= 1.15 * floor_b and eng_s <= 1.15 * floor_s
     for i in range(3, n):
         assert np.array_equal(got[i], got[i % 3]), f"slot {i} differs from slot {i % 3}"
     assert np.abs(got[:3] - want16).max() > 0.05      # e4m3 layers did run
+
+
+def test_fp8_plan_holds_the_bar_of_its_own_reproducibility(rmr, oracle, packs, images):
+    """Row g's ABSOLUTE bar.  The north-star tolerance for detections -- IoU >= 0.99 with identical class ids -- is held by
+    the f16 plan (test_detect_matches_oracle_postprocess).  An e4m3 plan cannot hold it against ANY second implementation:
+    profiles/r05_fp8_parity_study.txt has the fp8 oracle against the same oracle with every convolution result moved by
+    2^-22 of its value (another f32 summation order, nothing else) at 0-2 of 14-20 confident detections with IoU >= 0.99,
+    median IoU 0.92-0.97, boxes 1.2-2.0 px apart on average -- every e4m3 layer re-rounds to three mantissa bits.  What the
+    plan CAN hold, and what is asserted here against numbers computed in the test:
+      * the engine is no further from the oracle than that second exact implementation is (boxes, scores: <= 1.15x);
+      * every confident detection of the engine has the oracle's class at IoU >= 0.5, none is lost, and vice versa (one
+        borderline detection may cross the confidence threshold either way: the jittered oracle loses one as well);
+      * median IoU of the matched confident detections >= 0.75, at least half of them at IoU >= 0.8 (study: 0.87-0.98, 65-85 %)."""
+    from oracle import yolov8_ref as R
+    for which, nc in ((0, 1), (1, 12)):
+        det = rmr.Detector(packs[which], nc, (1920, 1080), 3, precision="fp8")
+        E, pps = det.infer(images)
+        det.close()
+        blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+        A = R.load(packs[which], fp8=True).forward(blobs)
+        J = R.load(packs[which], fp8=True, jitter=2.0 ** -22, jitter_seed=1).forward(blobs)
+        floor_b, floor_s = np.abs(J[:, :4] - A[:, :4]).mean(), np.abs(J[:, 4:] - A[:, 4:]).mean()
+        eng_b, eng_s = np.abs(E[:, :4] - A[:, :4]).mean(), np.abs(E[:, 4:] - A[:, 4:]).mean()
+        assert eng_b <= 1.15 * floor_b and eng_s <= 1.15 * floor_s, (eng_b, floor_b, eng_s, floor_s)
+
+        def matched(x, y):
+            ious, lost = [], 0
+            for i in range(len(images)):
+                dx, dy = oracle.postprocess(x[i], nc, 0.65, 0.5, pps[i]), oracle.postprocess(y[i], nc, 0.65, 0.5, pps[i])
+                for w in dx:
+                    if w["confidence"] < 0.6:
+                        continue
+                    best = max([netutil.iou_xywh(tuple(g)[:4], tuple(w)[:4]) for g in dy if g["label"] == w["label"]] or [0.0])
+                    ious.append(best)
+                    lost += best < 0.5
+            return np.array(ious), lost
+        for a, b, name in ((E, A, "engine -> oracle"), (A, E, "oracle -> engine")):
+            ious, lost = matched(a, b)
+            print(f"fp8 {['car', 'armor'][which]} {name}: {len(ious)} confident detections, lost {lost}, median IoU "
+                  f"{np.median(ious) if len(ious) else float('nan'):.3f}, >= 0.8: {(ious >= 0.8).sum()}; boxes {eng_b:.3f} px (floor {floor_b:.3f})")
+            assert lost <= 1
+            if len(ious) >= 4:
+                assert np.median(ious) >= 0.75 and (ious >= 0.8).sum() * 2 >= len(ious)
 
 
 def test_fp8_fused_e4m3_outputs_equal_the_quantiser_passes(rmr, packs, images, monkeypatch):
