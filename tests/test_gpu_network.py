@@ -544,9 +544,10 @@ def test_fp8_plan_holds_the_bar_of_its_own_reproducibility(rmr, oracle, packs, i
     from oracle import yolov8_ref as R
     for which, nc in ((0, 1), (1, 12)):
         det = rmr.Detector(packs[which], nc, (1920, 1080), 3, precision="fp8")
-        E, pps = det.infer(images)
+        E, _ = det.infer(images)
         det.close()
-        blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+        pre = [oracle.preprocess(im) for im in images]
+        blobs, pps = np.stack([q[0] for q in pre]), [q[1] for q in pre]
         A = R.load(packs[which], fp8=True).forward(blobs)
         J = R.load(packs[which], fp8=True, jitter=2.0 ** -22, jitter_seed=1).forward(blobs)
         floor_b, floor_s = np.abs(J[:, :4] - A[:, :4]).mean(), np.abs(J[:, 4:] - A[:, 4:]).mean()
