@@ -158,7 +158,10 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     const int gp0 = EW == 2 ? wk : 0;
     float4 bias[NREP][GPN * 2];
     u32x4 rres[MREP][NREP][GPN];
-    if (wide && wk < EW && !loader) {
+    // (wave tiles of three and more fragments fetch them at the epilogue instead: 72 registers held through the K loop would
+    // leave room for the fragments of one unit at a time)
+    constexpr bool PRELOAD = MREP * NREP <= 2;
+    const auto load_epilogue_operands = [&] {
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
 #pragma unroll
@@ -175,7 +178,8 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
                     for (int gg = 0; gg < GPN; ++gg)
                         rres[i][j][gg] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_lane + (unsigned)(i * 32 * a.res_cs + j * 32 + (gp0 + gg) * 16) * 2u, 0, 0);
         }
-    }
+    };
+    if (PRELOAD && wide && wk < EW && !loader) load_epilogue_operands();
 
     stamp(14);
     const u32x4 in_rsrc = {sgpr((unsigned)(size_t)a.in), sgpr((unsigned)((size_t)a.in >> 32) & 0xffffu), sgpr(in_lim), sgpr(0x00020000u)};
@@ -359,7 +363,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     constexpr int MAXV = NT <= 4 ? 512 : NT <= 8 ? 256 : NT <= 12 ? 168 : 128;
     constexpr int FRAGS = MREP * NREP;
     constexpr int NACC_WANT = FRAGS == 1 ? 4 : FRAGS < 4 ? 2 : 1;
-    constexpr int OTHER = 24 + NREP * 16 + FRAGS * 8 + (GATHER ? 2 * GCNT + 16 : (FRAGS > 2 ? 24 : 0));   // addresses and tables, the epilogue's bias and shortcut registers
+    constexpr int OTHER = 24 + (FRAGS <= 2 ? NREP * 16 + FRAGS * 8 : 0) + (GATHER ? 2 * GCNT + 16 : (FRAGS > 2 ? 24 : 0));   // addresses and tables, the epilogue's bias and shortcut registers
     constexpr int NACC = NACC_WANT * FRAGS * 16 + OTHER + 2 * (MREP + NREP) * 8 <= MAXV ? NACC_WANT : NACC_WANT > 2 ? 2 : 1;
     constexpr int GS_FIT = (MAXV - NACC * FRAGS * 16 - OTHER) / ((MREP + NREP) * 8);
     constexpr int GS_CAP = 16 / (MREP + NREP);
@@ -517,6 +521,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     if (!wide) {
         epilogue<MREP, NREP, 0, false, true>(a, acc[0], smem, 0, 0, m0, n0, wm, wn, lane);
     } else {
+        if constexpr (!PRELOAD) load_epilogue_operands();
         // conv_t32_common.h's wide epilogue with its loads hoisted to the top of the kernel: bias, SiLU, (+ shortcut in f32),
         // one rounding, lane pairs (l, l + 32) exchange halves so that each stores 16 bytes (8 consecutive channels).  With K
         // shared (WK > 1) this wave's half sits in registers 0 .. 7 of every fragment, otherwise half gg in registers 8 gg ..
@@ -693,14 +698,13 @@ int sb_geometry(const ConvArgs& a, const SbVariant& v, SbGeom& g) {
     } else {
         const int unit_bytes = (v.bm + v.bn) * 64;
         g.units = std::min(v.km * v.wk, g.total_units);
-        // more than one stage: the ring holds at least two (three with loader waves; fewer units per wave and stage where it would not)
-        while (g.units > v.wk && g.units < g.total_units && (v.loaders ? 3 : 2) * g.units * unit_bytes > budget) g.units -= v.wk;
+        // more than one stage: the ring holds at least two (fewer units per wave and stage where it would not)
+        while (g.units > v.wk && g.units < g.total_units && 2 * g.units * unit_bytes > budget) g.units -= v.wk;
         g.stage_bytes = g.units * unit_bytes;
         g.stages = (g.total_units + g.units - 1) / g.units;
     }
     g.ns = std::min(g.stages, budget / g.stage_bytes);
     if (g.ns < 1 || (g.ns < 2 && g.stages > 1)) return 0;
-    if (v.loaders && g.ns < 3 && g.stages > g.ns) return 0;   // loaders run ahead of the computing waves: a ring of three at least
     g.mt = (a.M + v.bm - 1) / v.bm;
     g.nt = (a.Cout_pad + v.bn - 1) / v.bn;   // (a last tile of 16 channels: f32 views only, the stores beyond Cout_pad are dropped)
     // what the tiles of an XCD share: with the channel tile innermost an XCD reads its pixel rows once and every weight
