@@ -2,29 +2,32 @@
 // handful of armor crops) on v_mfma_f32_32x32x16_f16.  Replaces, for those launches, the layers of the TensorRT engine
 // behind /root/reference/src/detect/detector.h:122.
 //
-// Why another family: the throughput kernels (conv_t32 / conv_halo / conv_dma) stream K through a ring of 2-5 slices and
-// wait for every slice.  At batch 1 a layer has 25-150 workgroups and every slice is a FIRST touch (weights come from the
-// Infinity Cache / HBM, the activations were written by the other XCDs a few microseconds ago), so a tile's K loop is a
-// chain of miss latencies: conv_halo's 64 x 32 tile on M1600 N192 K1728 takes 12 us for 0.5 us of MFMA work
-// (profiles/r04_layer_profile_b1_v2.txt).  Here a workgroup puts its WHOLE operand set in flight at once, as far as the
-// 160 KiB of LDS go:
+// Why another family.  The throughput kernels (conv_t32 / conv_halo / conv_dma) are built for launches that fill the chip
+// for hundreds of microseconds.  A layer of a batch-1 frame is 0.5 us of MFMA work for the chip and took them 10-17 us; stamps
+// inside this kernel's first versions (profiles/r05_sb_stamps.txt, DESIGN.md section 4 "Batch 1") showed what those
+// microseconds are: not launches, not L2 misses (operands hot or cold in the L2: the same time; every DMA out of range: the
+// same timeline), but the INSTRUCTION STREAM of a workgroup's few waves -- a lone wave issues an instruction every 4-8 cycles,
+// a taken branch costs ~10 ns, dependent MFMAs wait 16 passes for each other -- and the CU's address unit, which takes one
+// LDS-DMA instruction per 16 cycles and holds the issuing wave meanwhile.  So:
 //
 //   * a STAGE is the unit of arrival: one 32-channel chunk with all nine taps and the tile's input range (halo form,
 //     3x3 / stride 1: the range [m0 - W - 1, m0 + BM + W + 1) staged once, taps as row shifts of the fragment reads), or a
 //     few (tap, chunk) units with their gathered pixel rows (gathered form: 1x1 layers and strided 3x3 layers, padding
-//     as out-of-range DMA offsets that arrive as zeros);
-//   * the ring holds as many stages as LDS allows (all of them for most layers of a batch-1 frame) and every one of
-//     them is issued before the first wait; a stage is refilled behind the barrier that retires it;
-//   * the wait for "my DMAs of stage s" is a counted vmcnt chosen at run time (a 64-way switch: the number of DMA
-//     instructions a wave has in flight behind a stage depends on the layer, not on the template);
-//   * small tiles (32 x 32 ... 128 x 64 outputs) so that a batch-1 layer has 150-600 workgroups, and the waves of a
-//     workgroup split K between them where the tile is too small to split otherwise (WK: unit g goes to wave g % WK;
-//     partial tiles meet in LDS, summed in wave order: deterministic);
+//     as out-of-range DMA offsets that arrive as zeros).  The ring holds as many stages as LDS allows -- all of them for
+//     most layers of a batch-1 frame;
+//   * loader waves issue the DMAs (tables decided once per tile: no branches, no divisions in the issue code), one stage
+//     ahead of the stage they wait for with a counted vmcnt chosen at run time (64-way switch), and report a landed stage
+//     through the workgroup barrier; the other waves only compute;
+//   * small tiles (32 x 32 ... 128 x 96 outputs) so that a batch-1 layer has 100-600 workgroups; the WK waves of a wave tile
+//     share its K range (unit g of a stage goes to wave g % WK), a stage's fragment reads are issued ahead of its MFMAs, which
+//     run on independent accumulator chains; the partial tiles meet in LDS, summed in wave order (deterministic), and two of
+//     the waves share the epilogue;
 //   * weights are read from the LDS images conv_t32 / conv_g32 already keep ([chunk][tap][Cout / 16][64 lanes][8],
 //     pack_conv_weights_t32): a weight DMA is one contiguous KiB; same row swizzle, same fragment reads, same epilogue
-//     (conv_t32_common.h).
+//     arithmetic (conv_t32_common.h);
+//   * several INDEPENDENT layers can leave in one launch (conv_sb_group_kernel: the Detect head's branches).
 //
-// The kernel body is a device function of (tile id): the stand-alone launch runs one tile per workgroup.
+// The kernel body is a device function of (tile, layer): the stand-alone launch runs one tile per workgroup.
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -99,11 +102,11 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
 //     wait behind a stage is a multiple of one wave-uniform number (a loop of scalar branches had cost 170 cycles per DMA);
 //   * bias and shortcut are fetched BEFORE the first DMA (loads retire in order: they have landed with stage 0), the
 //     epilogue is arithmetic and stores.
-// LW: 0 = every wave issues its share of the DMAs and computes; 4 / 8 = the first LW waves of the workgroup (one / two per SIMD)
-// only issue DMAs, a few stages ahead of the one the other WM * WN * WK waves compute (a wave gets an LDS-DMA instruction out
-// every ~130 cycles, the CU's address unit takes one every 16: it takes eight issuing waves to keep it busy): a wave that issues a stage's DMAs is held
-// at the address unit for 0.25 us (16 cycles per instruction and CU), which the symmetric form pays between the MFMAs of
-// every stage; a loader wave held there leaves its SIMD's issue slots to the computing wave beside it.
+// LW: 0 = every wave issues its share of the DMAs and computes; 4 / 8 = the first LW waves of the workgroup (one / two per
+// SIMD) only issue DMAs, one stage ahead of the stage they wait for, and the other WM * WN * WK waves only compute.  A wave gets
+// an LDS-DMA instruction out every ~130 cycles and is held at the CU's address unit meanwhile (which takes one per 16 cycles):
+// in the symmetric form every stage's MFMAs wait behind that stage's share of the issue (0.25 us); a loader wave held there
+// leaves its SIMD's issue slots to the computing wave beside it (M1600 N192 K1728: 9.1 -> 7.4 us per launch).
 template <int WM, int WN, int WK, int MREP, int NREP, bool GATHER, int KM, int LW>
 __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, const int m0, const int n0, unsigned char* smem, const unsigned lds0) {
     constexpr int NC = WM * WN * WK;          // computing waves
