@@ -363,14 +363,21 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
     // accumulator sets: four independent MFMA chains per wave where the registers allow (a 32x32x16 MFMA has a latency of 16
     // passes; chained on one accumulator the six MFMAs of a stage took 0.3 us).  Unit parity and K-step parity choose the set.
     // GS: units whose fragments are read together, ahead of their MFMAs -- as many as the wave's register budget holds.
-    constexpr int MAXV = NT <= 4 ? 512 : NT <= 8 ? 256 : NT <= 12 ? 168 : 128;
+    constexpr int MAXV = NT <= 8 ? 256 : NT <= 12 ? 168 : 128;   // (ArchVGPRs: the accumulators of these kernels never sit in AccVGPRs)
     constexpr int FRAGS = MREP * NREP;
     constexpr int NACC_WANT = FRAGS == 1 ? 4 : FRAGS < 4 ? 2 : 1;
-    constexpr int OTHER = 24 + (FRAGS <= 2 ? NREP * 16 + FRAGS * 8 : 0) + (GATHER ? 2 * GCNT + 16 : (FRAGS > 2 ? 24 : 0));   // addresses and tables, the epilogue's bias and shortcut registers
+    constexpr int OTHER = 40 + (FRAGS <= 2 ? NREP * 16 + FRAGS * 8 : 0) + (GATHER ? 2 * GCNT + 16 : (FRAGS > 2 ? 24 : 0));   // addresses and tables, the epilogue's bias and shortcut registers
     constexpr int NACC = NACC_WANT * FRAGS * 16 + OTHER + 2 * (MREP + NREP) * 8 <= MAXV ? NACC_WANT : NACC_WANT > 2 ? 2 : 1;
-    constexpr int GS_FIT = (MAXV - NACC * FRAGS * 16 - OTHER) / ((MREP + NREP) * 8);
-    constexpr int GS_CAP = 16 / (MREP + NREP);
-    constexpr int GS = GS_FIT < 1 ? 1 : (GS_FIT < GS_CAP ? (GS_FIT < KM ? GS_FIT : KM) : (GS_CAP < KM ? GS_CAP : KM));
+    // one register set holds GS units; with several groups per stage a second set lets the next group's reads travel under this
+    // group's MFMAs (PIPE), where the budget has room for two sets of at least one unit... and the stage more than one group
+    constexpr int UNIT_REGS = (MREP + NREP) * 8;
+    constexpr int ROOM = MAXV - NACC * FRAGS * 16 - OTHER;
+    constexpr int GS_CAP = 16 / (MREP + NREP) < 1 ? 1 : 16 / (MREP + NREP);
+    constexpr int GS_ONE = ROOM / UNIT_REGS < 1 ? 1 : (ROOM / UNIT_REGS < GS_CAP ? ROOM / UNIT_REGS : GS_CAP);   // single set
+    constexpr int GS_TWO = ROOM / (2 * UNIT_REGS) < GS_CAP ? ROOM / (2 * UNIT_REGS) : GS_CAP;                       // two sets
+    constexpr bool PIPE = GS_ONE < KM && GS_TWO >= 1;
+    constexpr int GS_RAW = PIPE ? GS_TWO : GS_ONE;
+    constexpr int GS = GS_RAW < KM ? GS_RAW : KM;
     floatx16 acc[NACC][MREP][NREP];
 #pragma unroll
     for (int c = 0; c < NACC; ++c)
@@ -406,14 +413,18 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
             continue;
         }
 #endif
-        // GS units at a time: every fragment read of the group is issued before its first MFMA (left alone the compiler keeps
-        // one read in flight and every MFMA waits for the LDS latency of its own operands)
-#pragma unroll
-        for (int k0 = 0; k0 < KM; k0 += GS) {
-            half8 x0[GS][MREP], x1[GS][MREP], w0[GS][NREP], w1[GS][NREP];
+        // GS units at a time: every fragment read of a group is issued before its first MFMA (left alone the compiler keeps
+        // one read in flight and every MFMA waits for the LDS latency of its own operands), and where a stage has several
+        // groups the reads of group g + 1 are issued BEFORE the MFMAs of group g (two register sets: the MFMAs wait with a
+        // counted lgkmcnt for their own group only)
+        constexpr int NG = (KM + GS - 1) / GS;
+        half8 x0[2][GS][MREP], x1[2][GS][MREP], w0[2][GS][NREP], w1[2][GS][NREP];
+        const auto read_group = [&](auto GC) {
+            constexpr int gi = decltype(GC)::value;
+            constexpr int bsel = gi & 1;
 #pragma unroll
             for (int kk = 0; kk < GS; ++kk) {
-                const int k = k0 + kk;
+                const int k = gi * GS + kk;
                 if (k >= KM) continue;
                 const int uu = wk + k * WK;          // wave-uniform
                 const bool live = uu < nu;
@@ -425,8 +436,8 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
 #pragma unroll
                     for (int i = 0; i < MREP; ++i) {
                         const int sel = live ? ub + arow[i] : g.zero_off;
-                        x0[kk][i] = *(const half8*)(smem + sel);
-                        x1[kk][i] = *(const half8*)(smem + (sel ^ 32));
+                        x0[bsel][kk][i] = *(const half8*)(smem + sel);
+                        x1[bsel][kk][i] = *(const half8*)(smem + (sel ^ 32));
                     }
                 } else {
                     const int ky = (u * 11) >> 5, kx = u - ky * 3;
@@ -437,39 +448,47 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
                         const int row = arow[i] + shift;
                         const int at = sb + row * 64 + ((kq ^ ((row >> 2) & 3)) << 4);
                         const int sel = (live && ((amask[i] >> u) & 1u)) ? at : g.zero_off;
-                        x0[kk][i] = *(const half8*)(smem + sel);
-                        x1[kk][i] = *(const half8*)(smem + (sel ^ 32));
+                        x0[bsel][kk][i] = *(const half8*)(smem + sel);
+                        x1[bsel][kk][i] = *(const half8*)(smem + (sel ^ 32));
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < NREP; ++j) {
-                    w0[kk][j] = *(const half8*)(smem + wb + j * 2048);
-                    w1[kk][j] = *(const half8*)(smem + ((wb + j * 2048) ^ 32));
+                    w0[bsel][kk][j] = *(const half8*)(smem + wb + j * 2048);
+                    w1[bsel][kk][j] = *(const half8*)(smem + ((wb + j * 2048) ^ 32));
                 }
             }
+        };
+        read_group(tap_c<0>{});
+        static_for<0, NG>([&](auto GC) {
+            constexpr int gi = decltype(GC)::value;
+            constexpr int bsel = gi & 1;
+            if constexpr (PIPE && gi + 1 < NG) read_group(tap_c<gi + 1>{});
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < GS; ++kk) {
-                if (k0 + kk >= KM) continue;
+                if (gi * GS + kk >= KM) continue;
 #pragma unroll
                 for (int i = 0; i < MREP; ++i)
 #pragma unroll
                     for (int j = 0; j < NREP; ++j) {
                         constexpr int c0 = 0;
-                        const int c = NACC == 4 ? 2 * ((k0 + kk) & 1) : c0;
-                        acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kk][j], x0[kk][i], acc[c][i][j], 0, 0, 0);
+                        const int c = NACC == 4 ? 2 * ((gi * GS + kk) & 1) : c0;
+                        acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[bsel][kk][j], x0[bsel][kk][i], acc[c][i][j], 0, 0, 0);
                     }
 #pragma unroll
                 for (int i = 0; i < MREP; ++i)
 #pragma unroll
-                    for (int j = 0; j < NREP; ++j)
-                    {
-                        const int c = NACC == 4 ? 2 * ((k0 + kk) & 1) + 1 : NACC - 1;
-                        acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kk][j], x1[kk][i], acc[c][i][j], 0, 0, 0);
+                    for (int j = 0; j < NREP; ++j) {
+                        const int c = NACC == 4 ? 2 * ((gi * GS + kk) & 1) + 1 : NACC - 1;
+                        acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[bsel][kk][j], x1[bsel][kk][i], acc[c][i][j], 0, 0, 0);
                     }
             }
-            if (k0 + GS < KM) __builtin_amdgcn_sched_barrier(0);
-        }
+            if constexpr (gi + 1 < NG) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!PIPE) read_group(tap_c<gi + 1>{});
+            }
+        });
         slot = slot + 1 == g.ns ? 0 : slot + 1;
     }
 #pragma unroll
