@@ -267,6 +267,7 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
         }
     }
     const int d_stage = GATHER ? GCNT : WCNT + na_w;   // DMAs per wave and stage
+    const unsigned slab_inv = a.in_slab_c ? 65536u / (unsigned)a.in_slab_c + 1u : 0u;   // c / in_slab_c = (c * slab_inv) >> 16 for c < 2048
 
     const auto issue = [&](int s, int slot) {
         const unsigned base = lds0 + (unsigned)(slot * g.stage_bytes);
@@ -295,7 +296,12 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
                     t = gu - cc * 9;
                 }
                 const int ky = (t * 11) >> 5, kx = t - ky * 3;
-                const unsigned tap_off = (unsigned)(ky * W + kx) * cs2 + (unsigned)cc * 64u;
+                // the chunk's 16-byte piece of this lane: channels c .. c + 7 of the input; with planar channel groups (slabs: a C2f's
+                // chunks, 1x1 layers only) they live in slab c / in_slab_c -- slab_inv = 0 without slabs, so the same arithmetic
+                // gives cc * 64 bytes into the pixel
+                const unsigned c8 = (unsigned)cc * 32u + (unsigned)lch * 8u;
+                const unsigned slab = (c8 * slab_inv) >> 16;
+                const unsigned tap_off = (unsigned)(ky * W + kx) * cs2 + slab * a.in_slab_stride + (c8 - slab * (unsigned)a.in_slab_c) * 2u - (unsigned)lch * 16u;
                 const unsigned voff = g_pix[i] ? (live && ((g_ok[i] >> t) & 1u) ? g_base[i] + tap_off : OOB) : (live ? lane16 : OOB);
                 const unsigned soff = g_pix[i] ? 0u : (unsigned)(gu * nblk_all) * 1024u + g_wsrc[i];
                 if (g_pix[i])
@@ -551,6 +557,8 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
             __builtin_amdgcn_make_buffer_rsrc((void*)((_Float16*)a.out + (long)mw0 * a.out_cs), 0, view_bytes(a.out_cs), 0x00020000);
         const unsigned out_lane = (unsigned)(fr * a.out_cs + a.out_co + nw0 + kq * 8) * 2u;
         const bool has_res = a.res != nullptr;
+        const unsigned oslab_inv = a.out_slab_c ? 65536u / (unsigned)a.out_slab_c + 1u : 0u;
+        const __amdgpu_buffer_rsrc_t oslab_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0xfffffff0u, 0x00020000);   // (the launch checked the span)
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
 #pragma unroll
@@ -600,7 +608,17 @@ __device__ __forceinline__ void sb_tile(const ConvArgs& a, const SbGeom& g, cons
                         o.w[2] = s0[1];
                         o.w[3] = s1[1];
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(i * 32 * a.out_cs + j * 32 + (gp0 + gg) * 16) * 2u, 0, 0);
+                    if (a.out_slab_c) {
+                        // planar channel groups: the 8 channels of this store lie in slab ch / out_slab_c; rows past M must not
+                        // land in the next slab, so they go out of range by hand
+                        const unsigned ch = (unsigned)(nw0 + j * 32 + (gp0 + gg) * 16 + kq * 8);
+                        const unsigned so = (ch * oslab_inv) >> 16;
+                        const long row = (long)mw0 + i * 32 + fr;
+                        const unsigned off = row < a.M ? so * a.out_slab_stride + (unsigned)(row * a.out_cs + a.out_co + (ch - so * (unsigned)a.out_slab_c)) * 2u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(o.u, oslab_rsrc, off, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(o.u, out_rsrc, out_lane + (unsigned)(i * 32 * a.out_cs + j * 32 + (gp0 + gg) * 16) * 2u, 0, 0);
+                    }
                 }
     }
     stamp(6);
@@ -746,10 +764,22 @@ ConvTile conv_sb_tile(int id) { return ConvTile{kSbVariants[id].bm, kSbVariants[
 
 bool conv_sb_supported(const ConvArgs& a, int variant) {
     if (a.KH != a.KW || (a.KH != 1 && a.KH != 3) || a.pad != a.KH / 2 || a.Cin % 32 || a.Cin < 32 || !a.wt_t32) return false;
-    if (a.pre || a.in_slab_c || a.out_slab_c || a.in8 || a.out8 || a.split > 1) return false;
+    if (a.pre || a.in8 || a.out8 || a.split > 1) return false;
+    // planar channel groups (a C2f's chunks as slabs): the gathered form of the 1x1 layers, 16-byte pieces inside one slab, f16
+    // SiLU outputs (the wide epilogue), no shortcut, every view below 4 GB
+    const bool slabbed = a.in_slab_c || a.out_slab_c;
+    if (slabbed) {
+        if (a.KH != 1 || a.stride != 1 || a.res || a.out32 || !a.act || a.in_slab_c % 8 || a.out_slab_c % 8) return false;
+        if (a.in_slab_c && (a.Cin > 2040 || a.Cin % a.in_slab_c)) return false;
+        if (a.out_slab_c && (((a.out_cs | a.out_co) & 7) || a.Cout_pad % a.out_slab_c)) return false;
+        const double in_span = (a.in_slab_c ? (double)(a.Cin / a.in_slab_c - 1) * a.in_slab_stride : 0.0) + (double)a.N * a.H * a.W * a.in_cs * 2;
+        const double out_span = (a.out_slab_c ? (double)(a.Cout_pad / a.out_slab_c - 1) * a.out_slab_stride : 0.0) + (double)a.M * a.out_cs * 2;
+        if (in_span >= 3.9e9 || out_span >= 3.9e9) return false;
+    }
     if (variant < 0) return true;
     if (variant >= kNumSbVariants) return false;
     const SbVariant& v = kSbVariants[variant];
+    if (slabbed && !v.gather) return false;
     if (!v.gather && (a.KH != 3 || a.stride != 1 || a.Ho != a.H || a.Wo != a.W)) return false;
     if (a.Cout_pad % v.bn && !(a.out32 && a.Cout_pad % 16 == 0 && v.bn == 32)) return false;   // the class logits: 16 channels
     SbGeom g;

@@ -334,6 +334,30 @@ def test_network_on_the_gathered_kernels(rmr, packs, refs, images, oracle, monke
     assert sum(1 for t in tuned if 950 <= int(t[2]) < 980) >= 10
 
 
+def test_network_on_the_small_batch_kernels(rmr, packs, refs, images, oracle, monkeypatch, tmp_path):
+    """conv_sb.hip under the whole network: RMR_TUNE_ONLY=100000-199999 makes every layer it supports run on it (3x3 / stride-1
+    layers in the halo form; 1x1 and strided 3x3 layers with Cin % 32 == 0 in the gathered form, among them the 1x1 layers of the
+    slabbed C2fs, whose chunks are planar channel groups), grouped head launches included; both networks, three images (the
+    batch-1 frame's own sizes are covered by the detector tests); same oracle, same tolerance."""
+    import shutil
+    for which, nc in ((0, 1), (1, 12)):
+        pack = str(tmp_path / f"sb_{which}.rmrw")  # its own tuning cache
+        shutil.copy(packs[which], pack)
+        monkeypatch.setenv("RMR_TUNE_ONLY", "100000-199999")
+        n = 3
+        det = rmr.Detector(pack, nc, (2592, 2048), n, conf_thresh=0.5)
+        got, _ = det.infer(images)
+        one, _ = det.infer([images[1]])
+        det.close()
+        blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+        want = refs["car" if which == 0 else "armor"][1].forward(blobs)
+        for i in range(n):
+            _check_head(got[i:i + 1], want[i:i + 1], 2.0, 1e-2)
+        _check_head(one, want[1:2], 2.0, 1e-2)
+        tuned = [l.split() for l in open(pack + ".tune").read().splitlines()[1:]]
+        assert sum(1 for t in tuned if int(t[2]) >= 100000 or int(t[2]) == 398) >= 2 * 55, sorted({int(t[2]) for t in tuned})
+
+
 def test_fused_bottlenecks_equal_the_two_launches(rmr, packs, images, monkeypatch, tmp_path):
     """conv_wsf: the two 3x3 convolutions of a 48-channel C2f bottleneck (model.2) in one launch, the hidden tensor in LDS.
     Same f32 operation order and the same f16 rounding of the hidden tensor as the two launches, so the network's output
