@@ -358,6 +358,44 @@ def test_network_on_the_small_batch_kernels(rmr, packs, refs, images, oracle, mo
         assert sum(1 for t in tuned if int(t[2]) >= 100000 or int(t[2]) == 398) >= 2 * 55, sorted({int(t[2]) for t in tuned})
 
 
+def test_grouped_head_launches_equal_their_members_one_by_one(rmr, packs, images, monkeypatch, tmp_path):
+    """Round 5: the independent branches of the Detect head may leave in ONE conv_sb launch (kernel id 200000 + variant on a
+    group's first layer, 398 on the others).  A grouped launch runs the same tiles through the same code as its members launched
+    one by one with that variant, so the network output must be BIT-identical: the tuner's plan for one image (which groups the
+    head's small convolutions) against the same plan with every group taken apart."""
+    import shutil
+    pack = str(tmp_path / "car_groups.rmrw")
+    shutil.copy(packs[0], pack)
+    det = rmr.Detector(pack, 1, (1920, 1080), 1)      # tunes one image, writes <pack>.tune
+    det.infer([images[0]])
+    det.close()
+    lines = open(pack + ".tune").read().splitlines()
+    ent = [[int(v) for v in l.split()] for l in lines[1:]]
+    grouped = [e for e in ent if e[2] >= 200000]
+    assert grouped, "the tuner grouped nothing at one image (the six third convolutions of the head are 3x faster in one launch)"
+    apart, variant = [], None
+    for op, n, c in sorted(ent):
+        if c >= 200000:
+            variant = c - 200000
+            apart.append((op, n, 100000 + variant))
+        elif c == 398:
+            apart.append((op, n, 100000 + variant))
+        else:
+            apart.append((op, n, c))
+    plan_g, plan_a = str(tmp_path / "grouped.plan"), str(tmp_path / "apart.plan")
+    open(plan_g, "w").write("\n".join([lines[0]] + [f"{o} {n} {c}" for o, n, c in sorted(map(tuple, ent))]) + "\n")
+    open(plan_a, "w").write("\n".join([lines[0]] + [f"{o} {n} {c}" for o, n, c in apart]) + "\n")
+    outs = []
+    for plan in (plan_g, plan_a):
+        monkeypatch.setenv("RMR_PLAN", plan)
+        det = rmr.Detector(pack, 1, (1920, 1080), 1)
+        out, _ = det.infer([images[0]])
+        det.close()
+        outs.append(out)
+    assert np.isfinite(outs[0]).all()
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
 def test_fused_bottlenecks_equal_the_two_launches(rmr, packs, images, monkeypatch, tmp_path):
     """conv_wsf: the two 3x3 convolutions of a 48-channel C2f bottleneck (model.2) in one launch, the hidden tensor in LDS.
     Same f32 operation order and the same f16 rounding of the hidden tensor as the two launches, so the network's output
