@@ -413,6 +413,32 @@ def test_conv_sb_every_variant(rmr):
         rmr.conv2d(np.zeros((1, 8, 8, 64), np.float32), np.zeros((64, 64, 3, 3), np.float32), None, 2, 1, False, tile=SB)   # halo form, strided layer
 
 
+def test_conv_sb_seeded_sweep_of_shapes(rmr):
+    """The variants of conv_sb on layers nobody hand-picked: 120 seeded draws of (images, map size, channels, kernel, stride,
+    activation, shortcut, variant) -- odd maps, maps smaller than a tile, channel counts that leave a remainder of the channel
+    tile, one to nine 32-channel chunks -- each against torch in f32 (run_case's tolerance).  A variant may refuse a layer (ring
+    too small, Cout not a multiple of its tile); it must never run one wrong.  At least 70 of the draws must run."""
+    rng = np.random.default_rng(5)
+    n_var = 66
+    ran = 0
+    for case in range(120):
+        k = int(rng.choice([1, 3]))
+        stride = int(rng.choice([1, 2])) if k == 3 else 1
+        n = int(rng.integers(1, 6))
+        h, w = int(rng.integers(3, 45)), int(rng.integers(3, 45))
+        cin = 32 * int(rng.integers(1, 10))
+        cout = 32 * int(rng.integers(1, 9))
+        silu = bool(rng.integers(0, 2))
+        res = bool(rng.integers(0, 2)) and silu and stride == 1 and cin == cout
+        v = int(rng.integers(0, n_var // 2)) * 2 + (0 if (k == 3 and stride == 1) else 1)
+        try:
+            run_case(rmr, n, h, w, cin, cout, k, stride, silu, res, tile=SB + v, seed=300 + case)
+            ran += 1
+        except rmr.InvalidArgument:
+            pass
+    assert ran >= 70, ran
+
+
 def test_conv_g32_every_tile(rmr):
     # the gathered form of conv_t32 (conv_g32.hip, ids 950..): 1x1 layers and 3x3 layers of any stride, one
     # (tap, 32-channel chunk) stage = the tile's pixel rows at that tap + the weight slice, padding as

@@ -79,6 +79,44 @@ def test_network_output_matches_oracle(rmr, oracle, packs, refs, images, which, 
     det.close()
 
 
+@pytest.mark.parametrize("scale", ["s", "l"])
+def test_other_sizes_of_the_family_match_the_oracle(rmr, oracle, images, tmp_path, scale):
+    """The reference's engine is whatever ONNX the user exports (detector.cpp:74-99); the planner and the kernels are not tied to
+    YOLOv8m's widths.  YOLOv8s (32 .. 512 channels, one bottleneck per C2f of the first level) and YOLOv8l (64 .. 512, three to
+    six) against the f16-emulating oracle on the same seeded weights, at three images and at one (the small-batch kernels:
+    other channel counts, tile remainders and ring depths than the m network gives them).
+    The bar is the f16 floor of the pack itself: the oracle against the SAME oracle with every convolution result moved by
+    2^-22 of its value before its f16 rounding (another exact implementation: another f32 summation order).  On the uncalibrated
+    l pack that floor is 3x the m pack's (mean 0.10 px, largest 5-7 px: profiles/r05_size_probe.txt), and the engine sits on it."""
+    from oracle import yolov8_ref as R
+    from rm_radar_amd import weights as W
+    pack = W.make_synthetic_pack(str(tmp_path / f"{scale}.rmrw"), scale, 12, seed=21, cls_bias=-4.0)
+    det = rmr.Detector(pack, 12, (2592, 2048), 3, conf_thresh=0.5)
+    assert abs(det.flops_per_image - W.flops_per_image(scale, 12)) < 1e-3 * det.flops_per_image
+    got, _ = det.infer(images)
+    one, _ = det.infer([images[2]])
+    det.close()
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    want = R.load(pack, True).forward(blobs)
+    other = R.load(pack, True, jitter=2.0 ** -22, jitter_seed=1).forward(blobs)
+    assert np.isfinite(got).all()
+
+    def dist(a, b):
+        box, score = np.abs(a[:, :4] - b[:, :4]), np.abs(a[:, 4:] - b[:, 4:])
+        return box.mean(), np.quantile(box, 0.999), box.max(), score.max()
+
+    floor = dist(want, other)
+    for name, g, w, o in (("three images", got, want, other), ("one image", one, want[2:3], other[2:3])):
+        f = dist(w, o) if name == "one image" else floor
+        d = dist(g, w)
+        print(f"{scale}, {name}: engine vs oracle mean {d[0]:.4f} p99.9 {d[1]:.3f} max {d[2]:.3f} score {d[3]:.5f} | "
+              f"oracle vs jittered oracle {f[0]:.4f} {f[1]:.3f} {f[2]:.3f} {f[3]:.5f}")
+        assert d[0] <= 1.25 * f[0] + 0.01, (name, d, f)
+        assert d[1] <= 1.25 * f[1] + 0.05, (name, d, f)
+        assert d[2] <= 2.0 * f[2] + 0.5, (name, d, f)
+        assert d[3] <= 2.0 * f[3] + 2e-3, (name, d, f)
+
+
 @pytest.mark.parametrize("n", [64, 256])
 def test_large_batch_uses_the_same_network(rmr, packs, refs, images, oracle, n):
     """The kernels the autotuner picks for the throughput shapes (64 images per launch: wide halo
