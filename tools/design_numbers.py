@@ -101,6 +101,16 @@ def rows():
     m = gb and re.search(r"grid 150 x 448 threads, 16384 B per workgroup: per phase\s+flat barrier\s+([\d.]+) us\s+xcd barrier\s+([\d.]+) us\s+separate launches\s+([\d.]+) us", gb)
     add("a phase of 150 workgroups publishing 16 KB each: in-launch grid barrier vs launches", f"flat {m.group(1)} us, XCD-hierarchical {m.group(2)} us, "
         f"separate launches {m.group(3)} us" if m else None, f"{R}_grid_barrier.txt")
+    cp = text(f"{R}_chain_prototype.txt")
+    m = cp and re.findall(r"^(.+?)\s+grid\s+\d+ x\s+\d+ threads: three launches\s+([\d.]+) us\s+one launch with two grid barriers\s+([\d.]+) us\s+\(\s*([+-][\d.]+) %\)\s+outputs (\S+)", cp, re.M)
+    if m:
+        lo, hi = min(float(x[3]) for x in m), max(float(x[3]) for x in m)
+        k3 = next((x for x in m if "32 x 32, K over three waves" in x[0]), m[0])
+        add("the 3-op prototype (a C2f bottleneck chain at 20 x 20): one launch with two grid barriers against its three launches",
+            f"{lo:+.1f} ... {hi:+.1f} % over {len(m)} tile shapes (slower everywhere; the product's 32 x 32 / three-wave form: {k3[1]} -> {k3[2]} us), "
+            f"outputs {'bit-identical' if all(x[4].startswith('bit-identical') for x in m) else 'DIFFER'}", f"{R}_chain_prototype.txt")
+    else:
+        add("the 3-op prototype", None, f"{R}_chain_prototype.txt")
     f8 = jline(f"{R}_bench_config4_fp8_{TAG}.json")
     add("configs[4] (fp8 plan, 256 frames per step)", f"{f8['value']:.0f} frames/s, parity checked: {f8.get('parity_checked')}" if f8 else None, f"{R}_bench_config4_fp8_{TAG}.json")
     c3 = jline(f"{R}_bench_config3_{TAG}.json")
