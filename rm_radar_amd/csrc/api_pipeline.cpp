@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -47,8 +48,9 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
     std::vector<std::thread> locate;
     if (n_frames > 1)
         for (int s = 0; s < n_streams; ++s) locate.emplace_back(locate_stream, s);
-    else
-        locate_stream(0);  // one frame: a few launches, cheaper to enqueue here than to start a thread
+    // (one frame: a few launches, cheaper to enqueue on this thread than to start one -- but not in FRONT of the detector:
+    // detect_batch runs it once the car stage is in flight, so its ~45 us of host time travel under the car network)
+    const std::function<void()> locate_one_frame = [&] { locate_stream(0); };
     const auto join_all = [&] {
         for (auto& t : locate)
             if (t.joinable()) t.join();
@@ -58,9 +60,9 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
             if (e) return e;
         return nullptr;
     };
-    // thread B (the caller): two-stage detect over all frames of all streams.  As soon as the car boxes are
-    // known the searches are enqueued behind the locate work -- they need the boxes only -- so they run
-    // under the armor stage instead of after it.
+    // thread B (the caller): two-stage detect over all frames of all streams.  Once the car boxes are known and
+    // the armor stage is in flight, the searches are enqueued behind the locate work -- they need the boxes
+    // only -- so they run under the armor stage instead of after it, and so does the host time of enqueueing them.
     const int stride = cap;
     std::vector<rmr_robot> car_robots((size_t)n_frames * stride);
     std::vector<int> car_counts(n_frames, 0), car_index((size_t)n_frames * cap, -1);
@@ -83,7 +85,8 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
     };
     std::exception_ptr detect_error;
     try {
-        rd->impl.detect_batch(imgs, n_frames, forced_crops, forced_per_frame, out, n_out, cap, after_cars, car_index.data());
+        rd->impl.detect_batch(imgs, n_frames, forced_crops, forced_per_frame, out, n_out, cap, after_cars, car_index.data(),
+                              n_frames > 1 ? std::function<void()>() : locate_one_frame);
     } catch (...) {
         detect_error = std::current_exception();
     }
@@ -105,7 +108,7 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
         }
     if (timing) {
         const auto t_out = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[rmr step] since last exit %ld us | entry -> cars known %ld | after_cars %ld | armor stage + assembly %ld | search end %ld | merge %ld\n",
+        std::fprintf(stderr, "[rmr step] since last exit %ld us | entry -> cars known, armor stage enqueued %ld | after_cars %ld | rest of the armor stage + assembly %ld | search end %ld | merge %ld\n",
                      us(last_exit, t_in), us(t_in, t_cars), us(t_cars, t_cars_done), us(t_cars_done, t_det), us(t_det, t_search), us(t_search, t_out));
         last_exit = t_out;
     }

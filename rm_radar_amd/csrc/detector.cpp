@@ -121,14 +121,17 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
                            hipMemcpyDeviceToHost, stream_));
 }
 
-void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out) {
+void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out,
+                             const std::function<void()>& in_flight) {
     const int n = (int)descs.size();
     out.assign(n, {});
     if (n == 0) {        // Q10d: the reference would abort on an empty batch; return nothing --
         last_n_ = 0;     // and read_heads() must not hand out the previous call's heads as this call's
+        if (in_flight) in_flight();
         return;
     }
     enqueue(descs, true);
+    if (in_flight) in_flight();   // the GPU is busy with this batch: the caller's host work costs nothing here
     RMR_HIP(hipStreamSynchronize(stream_));
     bool extra = false;
     const rmr_detection* rows = (const rmr_detection*)heads_pin_.p;
@@ -246,7 +249,7 @@ RobotDetector::RobotDetector(const rmr_robot_detector_cfg& cfg)
 // RobotDetector::detect (detector.cpp:413-455) for n_frames independent frames
 void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int* forced_crops, int forced_per_frame,
                                  rmr_robot* out, int* n_out, int cap, const AfterCars& after_cars,
-                                 int* car_index_out) {
+                                 int* car_index_out, const std::function<void()>& car_in_flight) {
     if (n_frames <= 0 || !imgs || !out || !n_out || cap <= 0)
         fail(RMR_ERR_INVALID_ARGUMENT, "RobotDetector::detect: bad arguments");
     if (n_frames > cfg_.max_frames)
@@ -266,7 +269,7 @@ void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int*
     };
     {
         StageTag tag(1);
-        car_->detect_staged(descs, cars);
+        car_->detect_staged(descs, cars, car_in_flight);
     }
 
     if (forced_crops) {
@@ -283,7 +286,7 @@ void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int*
 
     for (int f = 0; f < n_frames; ++f)
         if ((int)cars[f].size() > cfg_.max_cars) cars[f].resize(cfg_.max_cars);  // Q10d
-    if (after_cars) after_cars(cars);
+    // (after_cars runs below, once the armor stage is in flight)
 
     // stage 2: one armor batch over every car crop of every frame (detector.cpp:417-425)
     descs.clear();
@@ -310,7 +313,7 @@ void RobotDetector::detect_batch(const rmr_image* imgs, int n_frames, const int*
     std::vector<std::vector<rmr_detection>> armors;
     {
         StageTag tag(2);
-        armor_->detect_staged(descs, armors);
+        armor_->detect_staged(descs, armors, after_cars ? std::function<void()>([&] { after_cars(cars); }) : std::function<void()>());
     }
 
     // Robot assembly + per-label de-duplication (detector.cpp:427-454)

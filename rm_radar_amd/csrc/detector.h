@@ -37,7 +37,10 @@ class Detector {
     void infer(const rmr_image* imgs, const int* crops, int n, float* net_out, rmr_preparam* pp);
 
     // the same on frames already resident on the device; descs carry src/crop only
-    void detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out);
+    // in_flight (optional): host work that needs nothing from this call, run after everything is enqueued and before the wait for
+    // the results -- it travels under the network instead of in front of it
+    void detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std::vector<rmr_detection>>& out,
+                       const std::function<void()>& in_flight = nullptr);
 
     // Parity hook: images [first, first + n) of the LAST call's network output ([4 + classes][anchors] f32 each, the
     // tensor handed to postprocess) and their letterbox parameters; returns the number of images of that call
@@ -81,14 +84,16 @@ class RobotDetector {
     size_t arena_bytes() { return car_->net().arena_bytes() + armor_->net().arena_bytes(); }
     Detector& stage(int i) { return i == 0 ? *car_ : *armor_; }
     // RobotDetector::detect (detector.cpp:413-455), batched over frames
-    // after_cars (optional) runs as soon as stage 1 is known -- the car boxes per frame, before the
-    // armor stage is enqueued; car_index_out (optional, [n_frames][cap]) names the car each output
-    // robot came from.  Together they let the caller start work that only needs the car boxes
-    // (Locator::search) while the armor stage runs.
+    // after_cars (optional) runs once stage 1 is known -- the car boxes per frame -- and the armor stage
+    // has been ENQUEUED (it only needs the boxes, so its host time travels under the armor network);
+    // car_index_out (optional, [n_frames][cap]) names the car each output robot came from.  Together
+    // they let the caller start work that only needs the car boxes (Locator::search) while the armor
+    // stage runs.  car_in_flight (optional) runs while the CAR stage is in flight: host work that needs
+    // nothing from the detector (a single frame's Locator::update / cluster enqueue).
     using AfterCars = std::function<void(const std::vector<std::vector<rmr_detection>>&)>;
     void detect_batch(const rmr_image* imgs, int n_frames, const int* forced_crops, int forced_per_frame,
                       rmr_robot* out, int* n_out, int cap, const AfterCars& after_cars = nullptr,
-                      int* car_index_out = nullptr);
+                      int* car_index_out = nullptr, const std::function<void()>& car_in_flight = nullptr);
 
    private:
     rmr_robot_detector_cfg cfg_;
