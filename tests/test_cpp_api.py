@@ -219,7 +219,7 @@ def test_reference_call_sequence_equals_the_python_mirror(tmp_path):
     assert "cloud is null." in res.stderr and "cloud is empty." in res.stderr   # locate.cpp:160-171
     lines = res.stdout.strip().split("\n")
     assert lines[-1] == "sample_calls ok"
-    assert lines[-2].split() == ["detect", str(len(one)), str(len(many))]
+    assert lines[-2].split() == ["detect", str(len(one)), str(len(many[0])), str(len(many))]
     it = iter(lines)
     n_robots = n_located = 0
     for i in range(n):

@@ -42,7 +42,7 @@ def rows():
     b = jline(f"{R}_bench_default_final.json")
     src = f"{R}_bench_default_final.json"
     if b:
-        add("frames/s, batch 64, K = 4 (headline, 20 steps)", f"{b['value']:.0f} ({b['ms_per_step']:.2f} ms per step; steady state over "
+        add(f"frames/s, batch 64, K = 4 (headline, {b['steps']} steps)", f"{b['value']:.0f} ({b['ms_per_step']:.2f} ms per step; steady state over "
             f"{b['steady_state']['seconds']:.0f} s: {b['steady_state']['value']:.0f})", src)
         add("kernel plan of that run", b["config"].get("kernel_plan"), src)
         add("p50 / p99 per frame at batch 1 (host inputs)", f"{b['p50_ms_batch1']:.3f} / {b['p99_ms_batch1']:.3f} ms ({b.get('latency_kernel_plan')})", src)
