@@ -32,7 +32,7 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
     const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
     };
-    std::chrono::steady_clock::time_point t_cars = t_in, t_cars_done = t_in, t_det = t_in, t_search = t_in;
+    std::chrono::steady_clock::time_point t_cars = t_in, t_cars_done = t_in, t_det = t_in, t_search = t_in, t_car_enq = t_in, t_loc_enq = t_in;
     // threads A: a Locator carries temporal state, so the frames of a stream go in order, one helper thread per
     // stream (each Locator enqueues on its own HIP stream); a frame's foreground list is kept in slot f of its
     // stream for the batched search
@@ -50,7 +50,11 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
         for (int s = 0; s < n_streams; ++s) locate.emplace_back(locate_stream, s);
     // (one frame: a few launches, cheaper to enqueue on this thread than to start one -- but not in FRONT of the detector:
     // detect_batch runs it once the car stage is in flight, so its ~45 us of host time travel under the car network)
-    const std::function<void()> locate_one_frame = [&] { locate_stream(0); };
+    const std::function<void()> locate_one_frame = [&] {
+        if (timing) t_car_enq = std::chrono::steady_clock::now();
+        locate_stream(0);
+        if (timing) t_loc_enq = std::chrono::steady_clock::now();
+    };
     const auto join_all = [&] {
         for (auto& t : locate)
             if (t.joinable()) t.join();
@@ -108,8 +112,12 @@ static void run_streams(rmr_robot_detector* rd, rmr_locator* const* locs, int n_
         }
     if (timing) {
         const auto t_out = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[rmr step] since last exit %ld us | entry -> cars known, armor stage enqueued %ld | after_cars %ld | rest of the armor stage + assembly %ld | search end %ld | merge %ld\n",
+        std::fprintf(stderr, "[rmr step] since last exit %ld us | entry -> cars known, armor stage enqueued %ld | after_cars %ld | rest of the armor stage + assembly %ld | search end %ld | merge %ld",
                      us(last_exit, t_in), us(t_in, t_cars), us(t_cars, t_cars_done), us(t_cars_done, t_det), us(t_det, t_search), us(t_search, t_out));
+        if (n_frames == 1)   // one frame: the locator's enqueue runs inside the detector's call, under the car stage
+            std::fprintf(stderr, " | of the first: frame staged + car stage enqueued %ld, locator enqueued %ld, wait + heads + armor enqueue %ld", us(t_in, t_car_enq),
+                         us(t_car_enq, t_loc_enq), us(t_loc_enq, t_cars));
+        std::fprintf(stderr, "\n");
         last_exit = t_out;
     }
 }

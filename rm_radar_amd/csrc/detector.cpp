@@ -4,7 +4,9 @@
 // 3 + 3 launches, one stream and one 202 KB D2H per image.
 #include "detector.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "postprocess.h"
 #include "robot.h"
@@ -45,8 +47,10 @@ const std::vector<FrameStage::Frame>& FrameStage::stage(hipStream_t s, const rmr
             any_host = true;
         }
         const size_t bytes = (size_t)im.stride * im.height;
-        std::memcpy(pin_.p + off, im.data, bytes);  // detector.cu:388: memcpy into pinned memory
         f.dev = dev_.p + off;
+        std::memcpy(pin_.p + off, im.data, bytes);  // detector.cu:388: memcpy into pinned memory
+        // (a single frame uploaded in 4 or 8 pieces, each behind the memcpy of the next: p50 1.919 / 1.94 against 1.911 ms -- the
+        // extra copies cost what the overlap returns)
         off += (bytes + 255) & ~(size_t)255;
     }
     if (off) RMR_HIP(hipMemcpyAsync(dev_.p, pin_.p, off, hipMemcpyHostToDevice, s));
@@ -66,6 +70,7 @@ Detector::Detector(const rmr_detector_cfg& cfg) : cfg_(cfg), ctx_(device_ctx(cfg
     int prio_lo = 0, prio_hi = 0;
     RMR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     RMR_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio_hi));
+    RMR_HIP(hipEventCreateWithFlags(&io_done_, hipEventDisableTiming));
     if (cfg.precision != RMR_PRECISION_F16 && cfg.precision != RMR_PRECISION_FP8)
         fail(RMR_ERR_INVALID_ARGUMENT, "Detector: precision %d is not one of RMR_PRECISION_*", cfg.precision);
     net_ = std::make_unique<Yolov8>(ctx_, cfg.engine_path, cfg.classes, cfg.input_width, cfg.input_height,
@@ -87,6 +92,7 @@ Detector::~Detector() {
         (void)hipStreamSynchronize(stream_);
         (void)hipStreamDestroy(stream_);
     }
+    if (io_done_) (void)hipEventDestroy(io_done_);
 }
 
 // preprocess (detector.cu:380-502) + enqueueV3 (detector.h:122) + the device half of
@@ -97,8 +103,10 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
         fail(RMR_ERR_CAPACITY, "Detector: batch of %d exceeds max_batch_size %d", n, cfg_.max_batch_size);
     ctx_.use();
     last_n_ = n;
-    // the pinned descriptor block is reused: make sure the previous call's copy is done
-    RMR_HIP(hipStreamSynchronize(stream_));
+    // the pinned descriptor block is reused: the previous call's copy of it must be done.  (Only that copy: a stream
+    // synchronisation here also waited for the frame upload enqueued a moment ago -- 25 us of a batch-1 frame during which
+    // the descriptors could have been written and the network launched behind it.)
+    RMR_HIP(hipEventSynchronize(io_done_));
     for (int i = 0; i < n; ++i) {
         LetterboxDesc& d = descs[i];
         const rmr_preparam p = make_preparam(d.crop_w, d.crop_h, cfg_.input_width, cfg_.input_height);
@@ -107,6 +115,7 @@ void Detector::enqueue(std::vector<LetterboxDesc>& descs, bool post) {
         pp_pin(n)[i] = p;
     }
     RMR_HIP(hipMemcpyAsync(io_dev_.p, io_pin_.p, pp_offset(n) + (size_t)n * sizeof(rmr_preparam), hipMemcpyHostToDevice, stream_));
+    RMR_HIP(hipEventRecord(io_done_, stream_));
     // letterbox (fill 128, 1/255) + network; the first layer samples the frames itself where it can
     net_->forward(stream_, n, descs_dev(), 128, 1 / 255.f);
     if (!post) return;

@@ -57,6 +57,7 @@ class Detector {
     rmr_detector_cfg cfg_;
     DeviceCtx& ctx_;
     hipStream_t stream_ = nullptr;
+    hipEvent_t io_done_ = nullptr;   // behind the H2D copy of the last call's descriptor block (the pinned side is reused)
     std::unique_ptr<Yolov8> net_;
     FrameStage stage_;
     static constexpr int kHeadRows = 64;  // rows per image fetched with the counts

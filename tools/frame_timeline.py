@@ -15,10 +15,11 @@ if os.environ.get("RMR_STEP_TIMING") != "1":   # the switch is read once by the 
     rows = [[int(v) for v in re.findall(r"(-?\d+)", l.split("]", 1)[1])] for l in p.stderr.splitlines() if l.startswith("[rmr step]")]
     import numpy as np
     a = np.array(rows[len(rows) // 4:], dtype=np.float64)
-    names = ["between calls", "entry -> cars known, armor stage enqueued (H2D, car stage, D2H)", "after_cars (search enqueue, under the armor stage)", "rest of the armor stage + assembly", "search end", "merge"]
+    names = ["between calls", "entry -> cars known, armor stage enqueued (H2D, car stage, D2H)", "after_cars (search enqueue, under the armor stage)", "rest of the armor stage + assembly", "search end", "merge",
+             "  of the first: frame staged + car stage enqueued", "  locator enqueued (under the car stage)", "  wait for the car stage + heads + crops + armor enqueue"]
     for i, n in enumerate(names):
         print(f"  {n:60s} median {np.median(a[:, i]):8.1f} us   p90 {np.percentile(a[:, i], 90):8.1f} us")
-    print(f"  sum of the medians inside a call: {np.median(a[:, 1:], axis=0).sum():.1f} us over {len(a)} frames")
+    print(f"  sum of the medians inside a call: {np.median(a[:, 1:6], axis=0).sum():.1f} us over {len(a)} frames")
     sys.exit(p.returncode)
 
 sys.path.insert(0, ROOT)
