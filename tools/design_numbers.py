@@ -111,6 +111,16 @@ def rows():
             f"outputs {'bit-identical' if all(x[4].startswith('bit-identical') for x in m) else 'DIFFER'}", f"{R}_chain_prototype.txt")
     else:
         add("the 3-op prototype", None, f"{R}_chain_prototype.txt")
+    ab = text(f"{R}_ab_r04_vs_{R}.txt")
+    rows_ab = ab and [l.split() for l in ab.splitlines() if l.startswith(("r04_", f"{R}_"))]
+    if rows_ab:
+        def mean(tag, col):
+            v = [float(r[col]) for r in rows_ab if r[0].startswith(tag)]
+            return sum(v) / len(v)
+        add("same box, alternating runs: the round-4 tree against this one (each under its committed plan)",
+            f"frames/s {mean('r04', 1):.0f} -> {mean(R, 1):.0f}; p50 {mean('r04', 3):.3f} -> {mean(R, 3):.3f} ms; p99 {mean('r04', 4):.3f} -> {mean(R, 4):.3f} ms", f"{R}_ab_r04_vs_{R}.txt")
+    else:
+        add("same-box A/B against the round-4 tree", None, f"{R}_ab_r04_vs_{R}.txt")
     f8 = jline(f"{R}_bench_config4_fp8_{TAG}.json")
     add("configs[4] (fp8 plan, 256 frames per step)", f"{f8['value']:.0f} frames/s, parity checked: {f8.get('parity_checked')}" if f8 else None, f"{R}_bench_config4_fp8_{TAG}.json")
     c3 = jline(f"{R}_bench_config3_{TAG}.json")
