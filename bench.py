@@ -92,6 +92,8 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=0, help="frame height, e.g. --size 1920 --height 1080 for configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--latency-frames", type=int, nargs=2, default=(200, 2000), metavar=("WARMUP", "TIMED"),
+                    help="batch-1 latency leg: untimed and timed frames (SURVEY 8d: 200 + 2000)")
     ap.add_argument("--cpu-frames", type=int, default=1, help="cpu_baseline: timed frames per worker")
     ap.add_argument("--cpu-workers", type=int, default=0, help="cpu_baseline: frames in flight (0 = cores / 4)")
     ap.add_argument("--launch-order", default="", help="write the enqueue order of the profiled launches (layer, FLOPs, bytes) to this "
@@ -109,8 +111,9 @@ def parse(argv=None):
                     "streams, each with its own Locator state (background image + depth ring in HBM), one detector batch over all")
     ap.add_argument("--dtype", choices=("f16", "fp8"), default="f16",
                     help="fp8 = BASELINE configs[4]: e4m3 weights and activations in the 3x3 layers of backbone and neck")
-    ap.add_argument("--config", type=int, default=2, help="BASELINE configs index: 2 = 640x640 + 30k points; 3 = one 1920x1080 "
-                    "stream + 100k-point clouds per GPU")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE configs index: 1 = batch 1 on the reference sample's 2592x2048 "
+                    "frames + 10k-point clouds from host memory (latency); 2 = 640x640 + 30k points; 3 = one 1920x1080 "
+                    "stream + 100k-point clouds per GPU; 4 = the fp8 plan at 256 frames per step")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST HOOK (tests/test_gpu_bench_step.py): every rank computes on GPU 0, the process group is gloo and the "
                          "robot-record exchange the C-ABI FILE transport -- the whole N > 1 control flow of main() (shards per rank, "
@@ -121,6 +124,8 @@ def parse(argv=None):
                          "transport), barriers, max-over-ranks clock and JSON assembly run for real on CPU; the GPU step is replaced "
                          "by a stand-in that only fabricates robot records.  The line says \"stub\": true and measures nothing")
     args = ap.parse_args(argv)
+    if args.config == 1:   # the reference sample's frames: 2592 x 2048 (samples/main.cpp:12), one frame per call
+        args.size, args.height, args.batch = 2592, 2048, 3
     if args.config == 3:
         args.size, args.height, args.points = 1920, 1080, 100000
     if args.config == 4:   # fp8-MFMA weights, batch = 256
@@ -165,6 +170,8 @@ def intrinsic(args):
     w, h = frame_size(args)
     if (w, h) == (640, 640):
         return scenes.K640
+    if (w, h) == scenes.SAMPLE_SIZE:
+        return scenes.SAMPLE_K     # samples/main.cpp:13-14
     f = 416.0 * w / 640.0
     return np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
 
@@ -196,7 +203,7 @@ def make_inputs(args, rank):
     return images, clouds, rects
 
 
-def step_parity_leg(args, rmr, rdet, frames, forced, clouds, local):
+def step_parity_leg(args, rmr, rdet, frames, forced, clouds, local, images=None, packs=None):
     """Part of the cpu_baseline leg (the only place bench.py touches the oracle, and only as the checker): ONE more step
     of the timed configuration on a fresh Locator, compared with the CPU oracle frame by frame -- located XYZ / presence
     of every robot (<= 1e-3 m) and the robot assembly on the step's own armor heads (bit-exact); tests/step_parity.py,
@@ -211,6 +218,13 @@ def step_parity_leg(args, rmr, rdet, frames, forced, clouds, local):
         robots, counts = rmr.run_batch(rdet, loc, frames, None, forced)
         cpu = step_parity.oracle_locator(oracle, size, intrinsic(args), scenes.SAMPLE_L2C)
         stat = step_parity.check_step(oracle, rmr, rdet, cpu, robots, counts, clouds, forced)
+        stat["network_checked"] = False
+        if images is not None and packs is not None:
+            # the NETWORK of this very step, under the plan it was timed with: one car head and three armor heads against
+            # the torch oracle (f16-emulating; fp8: the round-5 bar) -- a wrong entry in a committed plan turns this red
+            net = step_parity.check_network(oracle, rdet, images, forced, packs, args.dtype)
+            stat["network_checked"] = True
+            stat["network"] = net
         return True, {k: (round(v, 9) if isinstance(v, float) else v) for k, v in stat.items()}
     except AssertionError as e:
         return False, {"error": str(e)[:300]}
@@ -257,29 +271,73 @@ def cpu_baseline(args, packs, images, clouds, rects):
         for r in rects[f]:
             loc.search(tuple(float(v) for v in r))
 
-    def run(per_worker, first):
-        def work(w):
-            torch.set_num_threads(threads)   # the intra-op team of THIS calling thread
-            for i in range(per_worker):
-                one_frame(w, (first + w * per_worker + i) % args.batch)
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(workers) as ex:
-            list(ex.map(work, range(workers)))
-        return time.perf_counter() - t0
-
-    # one UNTIMED frame per worker first: oneDNN's primitive creation / JIT for the two shapes and the spin-up of each worker's
-    # intra-op team would otherwise sit inside a one-frame sample and bias the CPU figure downward
+    # ONE executor for the warm-up and the timed pass (the timed pass's threads must be the warmed ones).  Untimed
+    # warm-up: worker 0 runs one whole frame alone (oneDNN's primitive creation / JIT for the two shapes -- the primitive cache
+    # is process-wide), every other worker one tiny convolution (the spin-up of its own intra-op team).  Round 5 warmed with a
+    # whole frame on EVERY worker: 38 s of the driver's 95 s for nothing the timed pass needs.
     per_worker = max(1, args.cpu_frames)
-    warm_dt = run(1, 0)
-    dt = run(per_worker, workers)
+
+    import threading
+    all_here = threading.Barrier(workers)   # every pool thread exists and takes exactly one warm-up task
+
+    def warm(w):
+        torch.set_num_threads(threads)   # the intra-op team of THIS calling thread
+        all_here.wait()
+        if w == 0:
+            one_frame(0, 0)
+        else:
+            torch.nn.functional.conv2d(torch.zeros(1, 8, 32, 32), torch.zeros(8, 8, 3, 3))
+
+    def work(w):
+        torch.set_num_threads(threads)
+        for i in range(per_worker):
+            one_frame(w, (workers + w * per_worker + i) % args.batch)
+
+    with ThreadPoolExecutor(workers) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(warm, range(workers)))
+        warm_dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        list(ex.map(work, range(workers)))
+        dt = time.perf_counter() - t0
     torch.set_num_threads(prev_threads)
     n = workers * per_worker
     return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "workers": workers, "threads_per_worker": threads,
             "sample": f"{n} frame(s) of the same workload ({workers} workers x {per_worker} frame(s), {threads} torch intra-op "
                       f"threads each; per frame 1 car + {args.crops} armor YOLOv8m forwards in PyTorch-CPU fp32, C oracle "
-                      f"pre/post/locate on the worker's own Locator stream), {dt:.1f} s, after one untimed warm-up frame per worker "
-                      f"({warm_dt:.1f} s)"}
+                      f"pre/post/locate on the worker's own Locator stream), {dt:.1f} s, after an untimed warm-up on the same "
+                      f"threads (one whole frame on worker 0, a tiny convolution on the others: {warm_dt:.1f} s)"}
+
+
+def stage_split(all_stats, scale=1.0):
+    """rmr.profile(...).read(by_stage=True) -> ms per stage of the hot path.  Stages run on different streams and
+    overlap (locate under detect), so the figures add up to more than the wall time."""
+    stage_ms = {"first layer + letterbox sampling (car + armor)": 0.0, "network, car stage": 0.0, "network, armor stage": 0.0,
+                "head decode": 0.0, "box decode + NMS + restore": 0.0, "locate: update (scatter + diff)": 0.0,
+                "locate: cluster": 0.0, "locate: search": 0.0, "other": 0.0}
+    for name, v in all_stats.items():
+        # "car|conv n64 ..." / "armor|conv n256 ...": the stage comes from the library (RobotDetector tags what it enqueues),
+        # not from the image count -- at batch 256 both stages launch 256-image shapes
+        stage, k = name.split("|", 1) if "|" in name else ("", name)
+        ms = v["total_ms"] * scale
+        if "stem" in k or k == "letterbox":
+            stage_ms["first layer + letterbox sampling (car + armor)"] += ms
+        elif k.startswith("conv ") or k in ("sppf_pools", "upsample2x", "quant_f8"):
+            stage_ms["network, car stage" if stage == "car" else "network, armor stage" if stage == "armor" else "other"] += ms
+        elif k == "head_decode":
+            stage_ms["head decode"] += ms
+        elif k == "postprocess":
+            stage_ms["box decode + NMS + restore"] += ms
+        elif k in ("loc_scatter", "loc_diff"):
+            stage_ms["locate: update (scatter + diff)"] += ms
+        elif k == "loc_cluster":
+            stage_ms["locate: cluster"] += ms
+        elif k == "loc_search":
+            stage_ms["locate: search"] += ms
+        else:
+            stage_ms["other"] += ms
+    return {k: round(v, 4) for k, v in stage_ms.items()}
 
 
 PLAN_DIR = os.path.join(ROOT, "profiles", "plans")
@@ -451,6 +509,162 @@ def main_stub(args):
     R.close()
 
 
+def main_config1(args):
+    """BASELINE configs[1]: the full pipeline at batch 1 on the reference sample's inputs -- three of its frames at their own
+    size (assets/images/{0,4,9}.jpg, 2592 x 2048 BGR u8, committed re-encoded under tests/golden/assets_images) with their
+    sample clouds (assets/clouds/N.pcd, 10 k points, tests/golden/assets_clouds.npz), the calibration of samples/main.cpp:12-22
+    and the sample's call order (main.cpp:87 background update first, then runOnce per frame, sample_radar.h:106-127).  Every
+    timed call takes the frame and the cloud from HOST memory: the 15.9 MB frame is staged and copied inside the clock, as
+    the reference's preprocess does (detector.cu:388-399).  Seeded synthetic weights (the reference ships no models), K = 4
+    injected crops per frame for the armor stage, a few hundred injected LiDAR returns per crop so that the
+    search has something to find.  Legs: (a) host inputs -> p50 / p99 (the metric); (b) the same frames resident in HBM ->
+    what staging + H2D cost; (c) the bare pinned H2D of one frame; (d) events around every launch -> first layer (samples
+    the 15.9 MB source) against the rest; (e) parity: the sequence against the CPU oracle, network heads included."""
+    import torch
+
+    import rm_radar_amd as rmr
+    import scenes
+    from rm_radar_amd import assets
+    from rm_radar_amd import weights as W
+    local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    gold = os.path.join(ROOT, "tests", "golden")
+    ids = (0, 4, 9)
+    frames = [np.ascontiguousarray(assets.read_image(os.path.join(gold, "assets_images", f"full_{i}.jpg"))) for i in ids]
+    size, Kc = scenes.SAMPLE_SIZE, scenes.SAMPLE_K
+    assert all(f.shape == (size[1], size[0], 3) and f.dtype == np.uint8 for f in frames)
+    data = np.load(os.path.join(gold, "assets_clouds.npz"))
+    rng = np.random.default_rng(9)
+    background = scenes.make_cloud(rng, 60000, Kc, scenes.SAMPLE_L2C, size)
+    K = max(args.crops, 1)
+    rects = crop_rects(rng, len(frames), K, size)
+    clouds = []
+    for f, i in enumerate(ids):
+        asset = np.zeros((10000, 4), np.float32)
+        asset[:, :3] = data[f"cloud{i}"]
+        spec = [(tuple(float(v) for v in r), 2000.0, 300) for r in rects[f]]
+        extra = scenes.make_cloud(rng, sum(sp[2] for sp in spec), Kc, scenes.SAMPLE_L2C, size, spec, zero_frac=0, far_frac=0)
+        clouds.append(np.ascontiguousarray(np.concatenate([asset, extra])))
+    n_pts = clouds[0].shape[0]
+
+    pack_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rmr_packs")
+    os.makedirs(pack_dir, exist_ok=True)
+    packs = (os.path.join(pack_dir, "car_r0.rmrw"), os.path.join(pack_dir, "armor_r0.rmrw"))
+    W.make_synthetic_pack(packs[0], "m", 1, seed=1, cls_bias=-6.0)
+    W.make_synthetic_pack(packs[1], "m", 12, seed=2, cls_bias=-6.0)
+    plan = apply_plan(args, packs)
+
+    def make():
+        rd = rmr.RobotDetector(packs[0], packs[1], size, 12, max_cars=K, opt_cars=K, device=local, max_frames=1, precision=args.dtype)
+        lc = rmr.Locator(size[0], size[1], Kc, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C, device=local, max_frames=1)
+        lc.update(background)   # main.cpp:87
+        return rd, lc
+    r1, l1 = make()
+    fc = [np.ascontiguousarray(np.asarray(rects[f], np.int32).reshape(1, -1, 4)) for f in range(len(frames))]
+    fb_host = [rmr.FrameBatch([frames[f]], [clouds[f]]) for f in range(len(frames))]
+    plan_note = "pinned (RMR_PLAN): " + " + ".join(plan) if plan else "autotuned on this box"
+    try:
+        rmr.run_batch(r1, l1, fb_host[0], None, fc[0])
+    except rmr.RmrError as e:
+        if "pinned plan" not in str(e):
+            raise
+        r1.close(), l1.close()
+        os.environ.pop("RMR_PLAN", None)
+        r1, l1 = make()
+        plan_note = "autotuned on this box (the committed plan has no entries for these batch sizes)"
+        rmr.run_batch(r1, l1, fb_host[0], None, fc[0])
+
+    def timed(fbs, n_warm, n_timed):
+        lat = []
+        for i in range(n_warm + n_timed):
+            f = i % len(fbs)
+            t0 = time.perf_counter()
+            rmr.run_batch(r1, l1, fbs[f], None, fc[f])
+            lat.append((time.perf_counter() - t0) * 1e3)
+        return np.array(lat[n_warm:])
+    n_warm, n_timed = args.latency_frames
+    # (a) host inputs: the configuration as specified
+    lat = timed(fb_host, n_warm, n_timed)
+    # (b) the same frames and clouds resident in HBM
+    d_frames = [torch.from_numpy(f).to(dev) for f in frames]
+    d_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
+    fb_dev = [rmr.FrameBatch([d_frames[f]], [d_clouds[f]]) for f in range(len(frames))]
+    lat_dev = timed(fb_dev, max(20, n_warm // 4), max(200, n_timed // 4))
+    # (c) the bare H2D of one frame from pinned memory
+    p_img = rmr.PinnedArray(frames[0].shape, np.uint8, device=local)
+    p_img.a[...] = frames[0]
+    ring = rmr.UploadRing(1, frames[0].nbytes + 4096, device=local)
+    ring.begin(0, [p_img.a]); ring.wait(0)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ring.begin(0, [p_img.a]); ring.wait(0)
+    h2d_ms = (time.perf_counter() - t0) / 20 * 1e3
+    ring.close(); p_img.close()
+    # (d) events around every launch, device-resident inputs, 30 frames
+    stage_ms = None
+    if not args.no_profile:
+        with rmr.profile(local) as prof:
+            for i in range(30):
+                rmr.run_batch(r1, l1, fb_dev[i % len(fb_dev)], None, fc[i % len(fb_dev)])
+            torch.cuda.synchronize()
+            stage_ms = stage_split(prof.read(by_stage=True), 1.0 / 30)
+    # (e) parity: a fresh stream (background first), the three frames in order, against the CPU oracle
+    parity_checked, parity = False, {"skipped": "--no-parity"}
+    if not args.no_parity:
+        import oracle
+        import step_parity
+        l1.close()
+        l1 = rmr.Locator(size[0], size[1], Kc, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C, device=local, max_frames=1)
+        l1.update(background)
+        cpu = oracle.Locator(size[0], size[1], Kc, scenes.SAMPLE_L2C, scenes.SAMPLE_W2C)
+        cpu.update(background)
+        try:
+            tot = {"frames": 0, "robots": 0, "located": 0, "max_xyz_err_m": 0.0, "assembly_frames": 0}
+            for f in range(len(frames)):
+                robots, counts = rmr.run_batch(r1, l1, fb_host[f], None, fc[f])
+                st = step_parity.check_step(oracle, rmr, r1, cpu, robots, counts, clouds[f:f + 1], fc[f])
+                for k in ("frames", "robots", "located", "assembly_frames"):
+                    tot[k] += st[k]
+                tot["max_xyz_err_m"] = max(tot["max_xyz_err_m"], st["max_xyz_err_m"])
+                if f == 0:
+                    tot["network"] = step_parity.check_network(oracle, r1, frames[:1], fc[0], packs, args.dtype,
+                                                               armor_slots=tuple(range(min(K, 3))))
+                    tot["network_checked"] = True
+            parity_checked, parity = True, {k: (round(v, 9) if isinstance(v, float) else v) for k, v in tot.items()}
+        except AssertionError as e:
+            parity_checked, parity = False, {"error": str(e)[:300]}
+    r1.close(), l1.close()
+    flops_frame = W.flops_per_image("m", 1) + K * W.flops_per_image("m", 12)
+    p50, p99 = float(np.percentile(lat, 50)), float(np.percentile(lat, 99))
+    p50d = float(np.percentile(lat_dev, 50))
+    result = {
+        "metric": "frames/sec detect+locate at batch=1 on the reference sample's 2592x2048 frames + 10k-pt clouds; p50 ms/frame",
+        "value": 1e3 / float(lat.mean()), "unit": "frames/s", "n_gpus": 1, "steps": int(n_timed), "warmup": int(n_warm),
+        "ms_per_step": float(lat.mean()), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "the reference's sample frames and clouds (committed fixtures), synthetic weights",
+        "config": {"workload": f"configs[1]: batch=1, {len(frames)} of the reference's sample frames ({size[0]}x{size[1]} BGR u8, 15.9 MB each) "
+                               f"+ their sample clouds ({n_pts} points: 10000 of the asset + {n_pts - 10000} injected returns) FROM HOST MEMORY per call, "
+                               f"sample calibration, background update first; car YOLOv8m + {K} injected armor crops/frame, {args.dtype} MFMA",
+                   "gflop_per_frame": round(flops_frame / 1e9, 3), "kernel_plan": plan_note},
+        "p50_ms_batch1": round(p50, 3), "p99_ms_batch1": round(p99, 3), "max_ms": round(float(lat.max()), 3),
+        "latency_sample": {"warmup_frames": int(n_warm), "timed_frames": int(n_timed)},
+        "inputs_resident_in_hbm": {"p50_ms": round(p50d, 3), "p99_ms": round(float(np.percentile(lat_dev, 99)), 3), "frames": int(len(lat_dev))},
+        "stage_split_ms_per_frame": {
+            "staging + H2D of frame and cloud (p50 host inputs - p50 HBM inputs)": round(p50 - p50d, 3),
+            "bare pinned H2D of one 15.9 MB frame": round(h2d_ms, 3),
+            "h2d_fraction_of_frame": round((p50 - p50d) / p50, 4),
+            "kernels (events around every launch, inputs in HBM)": stage_ms},
+        "parity_checked": parity_checked, "parity": parity,
+    }
+    if not args.no_cpu_baseline:
+        args.crops = K
+        result["cpu_baseline"] = cpu_baseline(args, packs, np.stack(frames), np.stack(clouds), rects)
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse(argv)
@@ -462,6 +676,8 @@ def main(argv=None):
         sys.exit(3)
     if args.stub_step:
         return main_stub(args)
+    if args.config == 1:
+        return main_config1(args)
     if args.launch_order:
         if os.path.exists(args.launch_order):
             os.remove(args.launch_order)
@@ -590,31 +806,7 @@ def main(argv=None):
             rmr.run_batch(rdet, loc, frames_fb, None, forced)
             torch.cuda.synchronize()
             all_stats = prof.read(by_stage=True)
-        stage_ms = {"first layer + letterbox sampling (car + armor)": 0.0, "network, car stage": 0.0, "network, armor stage": 0.0,
-                    "head decode": 0.0, "box decode + NMS + restore": 0.0, "locate: update (scatter + diff)": 0.0,
-                    "locate: cluster": 0.0, "locate: search": 0.0, "other": 0.0}
-        for name, v in all_stats.items():
-            # "car|conv n64 ..." / "armor|conv n256 ...": the stage comes from the library (RobotDetector tags what it enqueues),
-            # not from the image count -- at batch 256 both stages launch 256-image shapes
-            stage, k = name.split("|", 1) if "|" in name else ("", name)
-            ms = v["total_ms"]
-            if "stem" in k or k == "letterbox":
-                stage_ms["first layer + letterbox sampling (car + armor)"] += ms
-            elif k.startswith("conv ") or k in ("sppf_pools", "upsample2x", "quant_f8"):
-                stage_ms["network, car stage" if stage == "car" else "network, armor stage" if stage == "armor" else "other"] += ms
-            elif k == "head_decode":
-                stage_ms["head decode"] += ms
-            elif k == "postprocess":
-                stage_ms["box decode + NMS + restore"] += ms
-            elif k in ("loc_scatter", "loc_diff"):
-                stage_ms["locate: update (scatter + diff)"] += ms
-            elif k == "loc_cluster":
-                stage_ms["locate: cluster"] += ms
-            elif k == "loc_search":
-                stage_ms["locate: search"] += ms
-            else:
-                stage_ms["other"] += ms
-        stage_ms = {k: round(v, 3) for k, v in stage_ms.items()}
+        stage_ms = stage_split(all_stats)
 
     # ---- 5. host inputs: the step's frames + clouds over PCIe.  (a) the copy on its own; (b) the loop a capture host
     # would run: step i + 1's inputs travel from page-locked buffers into the other slot of an upload ring
@@ -793,7 +985,7 @@ def main(argv=None):
 
     # ---- the timed configuration checked against the oracle (part of the cpu_baseline leg; needs rdet alive) ----
     if rank == 0 and world == 1 and not args.no_parity and S == 1:
-        result["parity_checked"], result["parity"] = step_parity_leg(args, rmr, rdet, frames_fb, forced, clouds, local)
+        result["parity_checked"], result["parity"] = step_parity_leg(args, rmr, rdet, frames_fb, forced, clouds, local, images, packs)
     elif rank == 0:
         result["parity_checked"], result["parity"] = False, {"skipped": "runs with one rank and one stream, unless --no-parity"}
 
@@ -820,12 +1012,15 @@ def main(argv=None):
         fb1 = [rmr.FrameBatch([images[f]], [clouds[f]]) for f in range(B)]
         fc1 = [np.ascontiguousarray(np.asarray(rects[f], np.int32).reshape(1, -1, 4)) for f in range(B)]
         lat = []
-        for i in range(220):  # 20 warm-up + 200 timed frames
+        n_warm, n_timed = args.latency_frames
+        for i in range(n_warm + n_timed):  # 200 warm-up + 2000 timed frames
             f = i % B
             t0 = time.perf_counter()
             rmr.run_batch(r1, l1, fb1[f], None, fc1[f])  # the same native call, one frame
             lat.append((time.perf_counter() - t0) * 1e3)
-        lat = np.array(lat[20:])
+        lat = np.array(lat[n_warm:])
+        result["latency_sample"] = {"warmup_frames": n_warm, "timed_frames": n_timed,
+                                    "max_ms": round(float(lat.max()), 3), "p999_ms": round(float(np.percentile(lat, 99.9)), 3)}
         result["p50_ms_batch1"] = round(float(np.percentile(lat, 50)), 3)
         result["p99_ms_batch1"] = round(float(np.percentile(lat, 99)), 3)
         r1.close()

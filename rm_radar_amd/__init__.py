@@ -157,23 +157,40 @@ def conv2d(x_nhwc, w_oihw, bias, stride, pad, silu, residual=None, tile=-1, devi
 
 def pin_plan(tune_path, plan_path, batches):
     """Write a pinned plan (RMR_PLAN=<plan_path>) from a tuning cache: every layer runs, at each batch size in
-    `batches`, the kernel the cache chose for its LARGEST tuned batch.  One kernel per layer whatever the batch
-    means one f32 summation order per output value, so an image gives bit-identical results alone or inside
-    a batch; and nothing is timed when a plan is pinned, so two boxes launch the same kernels."""
+    `batches`, the kernel the cache chose at ONE tuned batch size -- the largest at which the cache has every layer.
+    One kernel per layer whatever the batch means one f32 summation order per output value, so an image gives
+    bit-identical results alone or inside a batch; and nothing is timed when a plan is pinned, so two boxes launch
+    the same kernels.  All entries come from the same batch size, so a grouped launch (200000 + v) and its members'
+    398 markers, or a fused bottleneck (340..) and its 399, stay together.  The small-batch family (100000 + v, and the
+    grouped launches) has a hard limit of tiles per launch that grows with the batch: a plan that carries such entries is
+    only written for batch sizes up to the one they were tuned at (ValueError beyond), instead of a plan whose entries
+    the library would drop at load time."""
     with open(tune_path) as f:
         header = f.readline()
-        best = {}
+        by_n = {}
         for line in f:
             op, n, choice = (int(v) for v in line.split())
-            # split-K (1000 * split + tile) reduces partial sums in an order that depends on the split: the
-            # plan takes the same tile without it
-            if choice < 100000:   # (100000 + variant = the small-batch family conv_sb: no split-K form)
-                choice %= 1000
-            if op not in best or n > best[op][0]:
-                best[op] = (n, choice)
+            by_n.setdefault(n, {})[op] = choice
+    if not by_n:
+        raise ValueError(f"{tune_path}: no tuned layers")
+    all_ops = set().union(*[set(d) for d in by_n.values()])
+    full = [n for n, d in by_n.items() if set(d) == all_ops]
+    if not full:
+        raise ValueError(f"{tune_path}: no batch size at which every layer is tuned")
+    n_ref = max(full)
+    best = {}
+    for op, choice in by_n[n_ref].items():
+        # split-K (1000 * split + tile) reduces partial sums in an order that depends on the split: the
+        # plan takes the same tile without it
+        if choice < 100000:   # (100000 + variant = the small-batch family conv_sb: no split-K form)
+            choice %= 1000
+        best[op] = choice
+    if any(c >= 100000 for c in best.values()) and max(batches) > n_ref:
+        raise ValueError(f"{tune_path}: the cache's choices at {n_ref} images include small-batch kernels (conv_sb), which cannot be "
+                         f"pinned for larger batches ({max(batches)}): tune at the largest batch the plan is for")
     with open(plan_path, "w") as f:
         f.write(header)
-        for op, (_, choice) in sorted(best.items()):
+        for op, choice in sorted(best.items()):
             for n in batches:
                 f.write(f"{op} {n} {choice}\n")
     return plan_path

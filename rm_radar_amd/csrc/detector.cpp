@@ -140,7 +140,16 @@ void Detector::detect_staged(std::vector<LetterboxDesc>& descs, std::vector<std:
         return;
     }
     enqueue(descs, true);
-    if (in_flight) in_flight();   // the GPU is busy with this batch: the caller's host work costs nothing here
+    if (in_flight) {   // the GPU is busy with this batch: the caller's host work costs nothing here
+        try {
+            in_flight();
+        } catch (...) {
+            // the network is still sampling the staged frames: nothing may unwind (and let the next call's upload overwrite
+            // them) before the stream has drained
+            (void)hipStreamSynchronize(stream_);
+            throw;
+        }
+    }
     RMR_HIP(hipStreamSynchronize(stream_));
     bool extra = false;
     const rmr_detection* rows = (const rmr_detection*)heads_pin_.p;

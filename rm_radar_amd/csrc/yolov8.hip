@@ -409,8 +409,15 @@ void Yolov8::tune_group(hipStream_t s, int g, int n, size_t img0) {
         sum_ms += ms;
     }
     tuned_dirty_ = true;
-    static const bool off = std::getenv("RMR_GROUPS") && std::atoi(std::getenv("RMR_GROUPS")) == 0;   // RMR_GROUPS=0: never group
-    if (off) return;
+    // RMR_GROUPS=0: never group (read per call, so a test can change it between detectors of one process)
+    if (const char* e = std::getenv("RMR_GROUPS"))
+        if (std::atoi(e) == 0) return;
+    // RMR_TUNE_ONLY=lo-hi pins a kernel family under the whole network: a grouped conv_sb launch may only replace the members
+    // when the range covers the grouped ids (or the conv_sb ids) -- otherwise 700-799 would still hand the head to conv_sb
+    if (const char* e = std::getenv("RMR_TUNE_ONLY")) {
+        int lo = 0, hi = 0;
+        if (sscanf(e, "%d-%d", &lo, &hi) == 2 && !(hi >= kSbGroupBase || (lo <= kSbBase && hi >= kSbBase))) return;
+    }
     const std::vector<ConvArgs> args = group_args(g, n);
     hipEvent_t e0, e1;
     RMR_HIP(hipEventCreate(&e0));
@@ -424,6 +431,13 @@ void Yolov8::tune_group(hipStream_t s, int g, int n, size_t img0) {
     table.alloc(host.size());
     for (int v = 0; v < conv_sb_num_variants(); ++v) {
         if (!conv_sb_group_supported(args.data(), (int)args.size(), v)) continue;
+        {   // the gate tune_conv applies to conv_sb: beyond a few workgroups per CU the throughput kernels' streams win, and
+            // 66 variants x 3 launches of a large batch are minutes of tuning for a group that cannot win
+            const ConvTile ct = conv_sb_tile(v);
+            long tiles = 0;
+            for (const ConvArgs& a : args) tiles += (long)((a.M + ct.bm - 1) / ct.bm) * ((a.Cout_pad + ct.bn - 1) / ct.bn);
+            if (tiles > 6L * ctx_.num_cus) continue;
+        }
         conv_sb_group_build(args.data(), (int)args.size(), v, host.data());
         RMR_HIP(hipMemcpy(table.p, host.data(), host.size(), hipMemcpyHostToDevice));
         float v_ms = 1e30f;

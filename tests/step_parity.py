@@ -86,3 +86,51 @@ def check_step(oracle, rmr, rdet, cpu_loc, robots_c, counts, clouds, rects, armo
                         assert g.armors is None
                 stat["assembly_frames"] += 1
     return stat
+
+
+def check_network(oracle, rdet, images, rects, packs, dtype="f16", car_slots=(0,), armor_slots=None, box_tol=2.0, score_tol=1e-2):
+    """The NETWORK of the step that was just run (under whatever kernel plan the caller pinned), held to the torch oracle
+    (oracle/yolov8_ref.py, the restatement of the engine behind src/detect/detector.h:122): a few head slots of the car batch
+    and of the armor batch are read back (rmr_robot_detector_read_heads) and compared with the oracle's forward of the same
+    letterboxed pixels on the same pack.  f16 plan: the f16-emulating oracle, boxes within `box_tol` px (mean 0.25), scores
+    within `score_tol` -- test_gpu_network._check_head's bars.  fp8 plan: the fp8-emulating oracle, no further than 1.15 x the
+    distance between two exact implementations of the plan (the oracle against itself with every convolution result moved by
+    2^-22), the absolute bar of round 5.  images: the step's frames (u8 HWC), rects: int [n_frames, K, 4] injected crops.
+    Returns counters; raises AssertionError at the first slot out of tolerance."""
+    from oracle import yolov8_ref as R
+    n_frames, K = len(images), rects.shape[1]
+    if armor_slots is None:
+        armor_slots = sorted({0, (n_frames * K) // 2 + 1, n_frames * K - 1}) if K > 0 else ()
+    stat = {"car_slots": list(car_slots), "armor_slots": list(armor_slots), "max_box_err_px": 0.0, "max_score_err": 0.0}
+    for stage, pack, slots in ((0, packs[0], car_slots), (1, packs[1], armor_slots)):
+        if not len(slots):
+            continue
+        blobs = []
+        for s in slots:
+            if stage == 0:
+                blobs.append(oracle.preprocess(np.asarray(images[s]))[0])
+            else:
+                f, k = divmod(s, K)
+                blobs.append(oracle.preprocess(np.asarray(images[f]), crop=tuple(int(v) for v in rects[f, k]))[0])
+        blobs = np.stack(blobs)
+        got = np.concatenate([rdet.read_heads(stage, s, 1)[0] for s in slots])
+        assert np.isfinite(got).all(), f"stage {stage}: non-finite head values"
+        if dtype == "f16":
+            want = R.load(pack, True).forward(blobs)
+            for i, s in enumerate(slots):
+                box, score = np.abs(got[i, :4] - want[i, :4]), np.abs(got[i, 4:] - want[i, 4:])
+                assert box.max() <= box_tol and box.mean() <= 0.25 and score.max() <= score_tol, \
+                    f"stage {stage} slot {s}: boxes {box.max():.3f} px (mean {box.mean():.3f}), scores {score.max():.5f} from the f16 oracle"
+                stat["max_box_err_px"] = max(stat["max_box_err_px"], float(box.max()))
+                stat["max_score_err"] = max(stat["max_score_err"], float(score.max()))
+        else:
+            want = R.load(pack, fp8=True).forward(blobs)
+            jit = R.load(pack, fp8=True, jitter=2.0 ** -22, jitter_seed=1).forward(blobs)
+            floor_b, floor_s = np.abs(jit[:, :4] - want[:, :4]).mean(), np.abs(jit[:, 4:] - want[:, 4:]).mean()
+            eng_b, eng_s = np.abs(got[:, :4] - want[:, :4]).mean(), np.abs(got[:, 4:] - want[:, 4:]).mean()
+            assert eng_b <= 1.15 * floor_b + 0.02 and eng_s <= 1.15 * floor_s + 1e-5, \
+                f"stage {stage}: engine {eng_b:.3f} px / {eng_s:.5f} from the fp8 oracle, two exact implementations {floor_b:.3f} / {floor_s:.5f}"
+            stat["max_box_err_px"] = max(stat["max_box_err_px"], float(eng_b))
+            stat["max_score_err"] = max(stat["max_score_err"], float(eng_s))
+            stat["bar"] = "mean distance from the fp8 oracle <= 1.15 x that of a second exact implementation"
+    return stat

@@ -57,6 +57,8 @@ def _run_steps(bench, oracle, step_inputs, packs, n_steps, device_inputs, assemb
         robots, counts = rmr.run_batch(rdet, loc, frames, None, forced)
         stats.append(step_parity.check_step(oracle, rmr, rdet, cpu, robots, counts, clouds, forced,
                                             armor_conf=det_kw.get("armor_conf_thresh", 0.5), max_head_bytes=assembly_bytes))
+        if len(stats) == 1:   # the step's own network against the torch oracle: one car head, three armor heads
+            stats[0]["network"] = step_parity.check_network(oracle, rdet, images, forced, packs, det_kw.get("precision", "f16"))
     rdet.close()
     loc.close()
     return stats
@@ -75,6 +77,25 @@ def test_headline_step_matches_oracle(bench, oracle, step_inputs, packs):
     # grouping (about 100 of the 256 crops: the synthetic armor network votes for few labels) is located
     assert stats[0]["located"] >= 64 and stats[1]["located"] >= 64
     assert all(s["labelled"] >= 32 and s["armors"] >= s["labelled"] for s in stats)
+
+
+def test_headline_step_under_the_committed_plan(bench, oracle, step_inputs, packs, monkeypatch):
+    """The step as the driver times it: bench.apply_plan pins profiles/plans/yolov8m_{car,armor}_f16.tune, and what
+    bench.step_parity_leg reports as parity.network_checked is computed here -- locate, assembly AND one car + three armor
+    heads of the step against the torch oracle, under the plan's kernels (64-image car chunk, 256-image armor chunk)."""
+    import shutil
+    monkeypatch.setenv("RMR_PLAN", "")
+    d = os.path.dirname(packs[0])
+    mine = tuple(shutil.copyfile(p, os.path.join(d, "planned_" + os.path.basename(p))) for p in packs)
+    args = step_inputs[0]
+    try:
+        assert bench.apply_plan(args, mine) is not None and os.environ.get("RMR_PLAN") == "1"
+        s = _run_steps(bench, oracle, step_inputs, mine, 1, device_inputs=True)[0]
+    finally:
+        os.environ.pop("RMR_PLAN", None)
+    assert s["frames"] == 64 and s["assembly_frames"] == 64 and s["max_xyz_err_m"] <= 1e-3
+    assert s["network"]["car_slots"] == [0] and len(s["network"]["armor_slots"]) == 3
+    assert s["network"]["max_box_err_px"] <= 2.0 and s["network"]["max_score_err"] <= 1e-2
 
 
 def test_headline_step_with_labels(bench, oracle, step_inputs, packs):

@@ -91,3 +91,24 @@ def test_pmc_traffic_finds_the_steps_launch_sequence(tmp_path):
     order.write_text("\n".join(lines) + "\n")
     period = ns["step_order"](str(order))
     assert [r[1] for r in period] == seq and period[0][2:] == (10.0, 20.0)
+
+
+def test_pin_plan_takes_every_entry_from_one_batch_size(tmp_path):
+    """a group's launch (200000 + v) and its members' 398 markers must come from the same tuned batch, split-K ids
+    lose their split, and small-batch kernels are not pinned for batches beyond the one they were tuned at."""
+    import rm_radar_amd as rmr
+    tune = tmp_path / "a.tune"
+    tune.write_text("rmr-tune 17 4 640 640 1 256 gfx950\n"
+                    "0 1 100040\n1 1 200009\n2 1 398\n3 1 2806\n"
+                    "0 4 806\n1 4 810\n2 4 812\n3 4 3810\n"
+                    "0 8 806\n1 8 810\n")                      # 8 images: only half the layers tuned -> not the reference size
+    plan = rmr.pin_plan(str(tune), str(tmp_path / "a.plan"), (1, 2, 4))
+    rows = [tuple(int(v) for v in l.split()) for l in open(plan).read().splitlines()[1:]]
+    assert rows == [(0, 1, 806), (0, 2, 806), (0, 4, 806), (1, 1, 810), (1, 2, 810), (1, 4, 810),
+                    (2, 1, 812), (2, 2, 812), (2, 4, 812), (3, 1, 810), (3, 2, 810), (3, 4, 810)]
+    small = tmp_path / "b.tune"
+    small.write_text("rmr-tune 17 3 640 640 1 256 gfx950\n0 1 100040\n1 1 200009\n2 1 398\n")
+    rows = open(rmr.pin_plan(str(small), str(tmp_path / "b.plan"), (1,))).read().splitlines()[1:]
+    assert rows == ["0 1 100040", "1 1 200009", "2 1 398"]   # the group stays whole
+    with pytest.raises(ValueError):
+        rmr.pin_plan(str(small), str(tmp_path / "c.plan"), (1, 64))
