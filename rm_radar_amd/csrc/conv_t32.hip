@@ -167,7 +167,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
         s_rsrc[j] = NW * (j + 1) <= NB ? wt_rsrc : NW * j >= NB ? in_rsrc : (s_isw[j] ? wt_rsrc : in_rsrc);
         s_wdst[j] = lds0 + ring_base + q * 1024;
         s_wsrc[j] = (unsigned)q * 1024u;
-        s_aidx[j] = q - NB;
+        // D * NW can exceed SLOTS (the four-wave tiles: 12 slots for 10 blocks per tap): a surplus slot fetches nothing.  (Until
+        // round 6 it fetched block t * A_SLOTS + A_SLOTS (+ 1) -- the next tap's first blocks, a second time: 12 of a chunk's
+        // 93 KiB of DMA on the 256 x 96 tile.)  An index past every range keeps it dead in every tap.
+        s_aidx[j] = q < SLOTS ? q - NB : 1 << 20;
     }
 
     // Two workgroups share a CU so that one's epilogue (two transcendentals per output value: a third of the
@@ -236,13 +239,18 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     __builtin_amdgcn_s_barrier();
 
     constexpr int NM = MREP * NREP;   // MFMAs per K-step
-    int slot = 0;                     // ring slot of the tap being computed
-    int abuf = 0;                     // input buffer of the chunk being computed
-    // the weight stream: slice gw of the tile whose channel-tile offset is w_tile is the next one to fetch
-    unsigned gw = g0 + R - 1;
-    unsigned gwoff = (unsigned)(g0 + R - 1) * wstep;
-    unsigned w_tile = (unsigned)(n0 / 16) * 1024u;
-    unsigned w_live = 1u;
+    // Scalar state of the K loop, kept to a handful of SGPRs with one or two SALU instructions per tap.  (Round 5's form --
+    // slot numbers multiplied out per tap, a slice counter compared with the tile's total in every tap, four selects behind
+    // it -- was 34 SALU instructions per tap, and the compiler computed all nine taps' worth in FRONT of a chunk's first MFMA
+    // and parked the results in VGPR lanes: 196 spilled SGPRs, 113 v_readlane + 28 v_writelane + 59 s_nop per chunk.)
+    int woff = 0;                               // ring slot of the tap being computed, as a byte offset
+    int woff_prev = (R - 1) * SLOT_BYTES;       // the slot the previous tap left: where this tap's weight DMAs land
+    int abuf = 0;                               // input buffer of the chunk being computed
+    // the weight stream: the next slice to fetch lies at byte offset wsoff (channel-tile offset + slice offset) of the packed
+    // weights; the stream runs R - 1 slices ahead of the MFMAs, so it crosses into the next tile's weights behind tap 9 - R of
+    // a tile's LAST chunk -- a compile-time tap, not a counter
+    unsigned wsoff = (unsigned)(n0 / 16) * 1024u + (unsigned)(g0 + R - 1) * wstep;
+    unsigned wv = lane16;                       // the weight DMAs' lane offset: OOB once the stream has run past the last tile
 
     for (;;) {
         if (prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
         // fragments of (tap 0, K-step 0): the slice and the range were waited for before the last barrier
         half8 xa[MREP], wa[NREP], xb[MREP], wb[NREP];
         int selx[MREP];
-        int wcur = wlane + slot * SLOT_BYTES;
+        int wcur = wlane + woff;
         {
             const int at = a_addr(abuf, 0);
 #pragma unroll
@@ -296,6 +304,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
             const bool a_live = in_tile || has_next;
             const int a_pl = in_tile ? pl : pln;
             const int a_cc = in_tile ? cc + 1 : 0;
+            const int na_live = a_live ? na : 0;                       // blocks of the range fetched during this chunk
+            const unsigned a_base = lds0 + (unsigned)abuf_next;        // where they land
             // One tap = 2 NM MFMAs (K-step 0, then K-step 1); everything else is placed by hand into the gaps
             // behind them (a 32x32x16 MFMA occupies the pipe for 32 cycles).  The fragments of a K-step are read
             // one K-step ahead: those of the next tap's K-step 0 BEFORE the barrier that opens that tap, so the
@@ -303,8 +313,6 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
             const auto tap = [&](auto T) {
                 constexpr int t = decltype(T)::value;
                 constexpr int tn = (t + 1) % 9;
-                const int slot_w = slot == 0 ? R - 1 : slot - 1;
-                const unsigned wv = w_live ? lane16 : OOB;
                 int at_n = 0;
                 __builtin_amdgcn_s_barrier();
                 // fillers of K-step 0: the K-step 1 fragments of this tap (pixels, then weights), D DMA slots, the
@@ -323,10 +331,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
                         constexpr int d = f - 2;
                         constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
                         constexpr bool a_tap = t < ATAPS;
-                        const unsigned w_lds = s_wdst[d] + slot_w * SLOT_BYTES, w_soff = s_wsrc[d] + w_tile + gwoff;
+                        const unsigned w_lds = s_wdst[d] + woff_prev, w_soff = s_wsrc[d] + wsoff;
                         const int ia = t * A_SLOTS + s_aidx[d];
-                        const bool alive = a_tap && a_live && ia < na;
-                        const unsigned a_lds = alive ? lds0 + abuf_next + ia * 1024 : scratch;
+                        const bool alive = a_tap && ia < na_live;
+                        const unsigned a_lds = alive ? a_base + ia * 1024 : scratch;
                         if constexpr (all_w) {
                             dma16s(wt_rsrc, sgpr(w_lds), wv, sgpr(w_soff));
                         } else if constexpr (all_a) {
@@ -344,9 +352,9 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
                         }
                     } else {
                         at_n = a_addr(t == 8 ? abuf_next : abuf, tn);
-                        const int slot_n = slot + 1 == R ? 0 : slot + 1;
-                        wcur = wlane + slot_n * SLOT_BYTES;
-                        slot = slot_n;
+                        woff_prev = woff;
+                        woff = woff + SLOT_BYTES == R * SLOT_BYTES ? 0 : woff + SLOT_BYTES;
+                        wcur = wlane + woff;
                     }
                 };
                 static_for<0, NM>([&](auto Kc) {
@@ -394,11 +402,12 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
                 // advance the weight stream; behind a tile's last slice comes the first one of the next tile
                 // (selects, not a branch: a tap must stay one basic block, or the scheduling pins above do not hold
                 // the MFMAs in place and the compiler sinks them towards the end of the chunk)
-                const unsigned wrap = 0u - (unsigned)(gw + 1 == (unsigned)total);   // all ones behind the tile's last slice
-                gw = (gw + 1) & ~wrap;
-                gwoff = (gwoff + wstep) & ~wrap;
-                w_tile ^= (w_tile ^ w_tile_next) & wrap;
-                w_live ^= (w_live ^ (unsigned)has_next) & wrap;
+                if constexpr (t == 9 - R) {
+                    wsoff = in_tile ? wsoff + wstep : w_tile_next;
+                    wv = in_tile ? wv : (has_next ? lane16 : OOB);
+                } else {
+                    wsoff += wstep;
+                }
             };
             tap(tap_c<0>{});
             tap(tap_c<1>{});

@@ -5,8 +5,12 @@
 #include "detector.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 #include "postprocess.h"
 #include "robot.h"
@@ -14,6 +18,61 @@
 namespace rmr {
 
 // ---- FrameStage ------------------------------------------------------------------------------------
+
+// The helper thread of a large frame's staging copy: it copies the odd pieces while the calling thread copies the even ones
+// and enqueues every piece's H2D in order.  One job at a time; done[i] is published with release order.
+struct FrameStage::Helper {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false, has_job = false;
+    uint8_t* dst = nullptr;
+    const uint8_t* src = nullptr;
+    size_t bytes = 0, piece = 0;
+    std::vector<std::atomic<int>> done;
+    Helper() : done(64) {
+        th = std::thread([this] {
+            for (;;) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return stop || has_job; });
+                if (stop) return;
+                has_job = false;
+                // the job's parameters as locals: behind its last store to done[] the thread touches nothing the next start()
+                // writes (the caller has by then seen every odd piece's flag)
+                uint8_t* const d = dst;
+                const uint8_t* const sp = src;
+                const size_t n = bytes, pc = piece;
+                std::atomic<int>* const flags = done.data();
+                lk.unlock();
+                size_t i = 1;
+                for (size_t o = pc; o < n; o += 2 * pc, i += 2) {
+                    std::memcpy(d + o, sp + o, std::min(pc, n - o));
+                    flags[i].store(1, std::memory_order_release);
+                }
+            }
+        });
+    }
+    ~Helper() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_one();
+        th.join();
+    }
+    void start(uint8_t* d, const uint8_t* s_, size_t n, size_t pc) {
+        const size_t pieces = (n + pc - 1) / pc;
+        if (done.size() < pieces) done = std::vector<std::atomic<int>>(pieces);
+        for (size_t i = 0; i < pieces; ++i) done[i].store(0, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            dst = d, src = s_, bytes = n, piece = pc, has_job = true;
+        }
+        cv.notify_one();
+    }
+};
+
+FrameStage::~FrameStage() { delete helper_; }
 
 const std::vector<FrameStage::Frame>& FrameStage::stage(hipStream_t s, const rmr_image* imgs, int n) {
     frames_.resize(n);
@@ -29,7 +88,16 @@ const std::vector<FrameStage::Frame>& FrameStage::stage(hipStream_t s, const rmr
         dev_.alloc(need);
         pin_.alloc(need);
     }
-    size_t off = 0;
+    // A large frame (the reference sample's 2592 x 2048 x 3 = 15.9 MB: 0.5 ms of memcpy + 0.3 ms of H2D, 30 % of a batch-1
+    // frame when they run one after the other: profiles/r06_bench_config1_a.json) travels in pieces, each piece's H2D behind
+    // the memcpy of the next, so the frame costs max(memcpy, H2D) + one piece: p50 2.67 -> 2.49 ms; the memcpy (0.5 ms for one
+    // thread) is then what is left, so a helper thread copies every other piece.  (640 x 640 frames: one piece -- uploading them
+    // in 4 or 8 pieces gave p50 1.919 / 1.94 against 1.911 ms, the extra copies cost what the overlap returns.)
+    static const size_t piece = [] {
+        const char* e = std::getenv("RMR_STAGE_PIECE_KB");
+        return (size_t)(e ? std::max(64, std::atoi(e)) : 2048) << 10;
+    }();
+    size_t off = 0, sent = 0;
     bool any_host = false;
     for (int i = 0; i < n; ++i) {
         const rmr_image& im = imgs[i];
@@ -48,12 +116,28 @@ const std::vector<FrameStage::Frame>& FrameStage::stage(hipStream_t s, const rmr
         }
         const size_t bytes = (size_t)im.stride * im.height;
         f.dev = dev_.p + off;
+        if (bytes >= 4 * piece) {
+            if (off > sent) RMR_HIP(hipMemcpyAsync(dev_.p + sent, pin_.p + sent, off - sent, hipMemcpyHostToDevice, s));
+            if (!helper_) helper_ = new Helper();
+            helper_->start(pin_.p + off, im.data, bytes, piece);
+            size_t i = 0;
+            for (size_t o = 0; o < bytes; o += piece, ++i) {
+                const size_t len = std::min(piece, bytes - o);
+                if (i & 1) {
+                    while (!helper_->done[i].load(std::memory_order_acquire)) __builtin_ia32_pause();
+                } else {
+                    std::memcpy(pin_.p + off + o, im.data + o, len);
+                }
+                RMR_HIP(hipMemcpyAsync(dev_.p + off + o, pin_.p + off + o, len, hipMemcpyHostToDevice, s));
+            }
+            off += (bytes + 255) & ~(size_t)255;
+            sent = off;
+            continue;
+        }
         std::memcpy(pin_.p + off, im.data, bytes);  // detector.cu:388: memcpy into pinned memory
-        // (a single frame uploaded in 4 or 8 pieces, each behind the memcpy of the next: p50 1.919 / 1.94 against 1.911 ms -- the
-        // extra copies cost what the overlap returns)
         off += (bytes + 255) & ~(size_t)255;
     }
-    if (off) RMR_HIP(hipMemcpyAsync(dev_.p, pin_.p, off, hipMemcpyHostToDevice, s));
+    if (off > sent) RMR_HIP(hipMemcpyAsync(dev_.p + sent, pin_.p + sent, off - sent, hipMemcpyHostToDevice, s));
     return frames_;
 }
 

@@ -14,6 +14,7 @@ namespace rmr {
 class FrameStage {
    public:
     explicit FrameStage(DeviceCtx&) {}
+    ~FrameStage();
     // returns, per image, a device pointer + geometry (device images pass through)
     struct Frame {
         const uint8_t* dev;
@@ -25,6 +26,9 @@ class FrameStage {
     DevBuf<uint8_t> dev_;
     PinnedBuf<uint8_t> pin_;
     std::vector<Frame> frames_;
+    // a large frame's memcpy into pinned memory is shared with one helper thread (started at the first such frame)
+    struct Helper;
+    Helper* helper_ = nullptr;
 };
 
 class Detector {
