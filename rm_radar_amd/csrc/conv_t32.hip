@@ -52,7 +52,7 @@ using namespace t32;
 // ABL (development builds only, -DRMR_T32_ABLATE): bit 0 = no MFMAs, 1 = no epilogue, 2 = epilogue without stores,
 // 3 = every DMA out of range (zeros arrive, no memory traffic), 4 = no fragment reads in the K loop.  Timing only.
 template <int WM, int WN, int MREP, int NREP, int A_SLOTS, int R, int EPI, int ABL = 0>
-__global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 2 : MREP == 1 ? 4 : 2)) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
+__global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN <= 4 ? 2 : MREP == 1 ? 4 : 2)) void conv_t32_kernel(const ConvArgs a, const int a_rows, const int n_tiles, const int stagger) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MREP * 32;
     constexpr int BN = WN * NREP * 32;
@@ -63,6 +63,15 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
     constexpr int ATAPS = 11 - R;               // taps that carry input-range blocks
     constexpr int STG_PITCH = NREP * 64 + 16;   // bytes per pixel row of the epilogue stage
     constexpr unsigned OOB = 0xffff0000u;
+    // UNI: every row of DMA slots has ONE role for all waves, known at compile time -- full weight blocks, then (where the
+    // weight blocks of a tap are half a row short) a row of HALF blocks (two waves share a KiB, lanes 0..31 each), then input
+    // blocks.  The four-wave tiles with A_SLOTS = 4: 256 x 96 is 6 weight blocks = one full row + one row of halves, + one
+    // row of input blocks.  Round 5 had row 1 mixed (waves 0-1 weights, waves 2-3 input): every operand of that DMA went
+    // through a select on the wave's role (two s_and + s_cselect pairs and a v_cndmask per tap), and row 2's last two slots
+    // fetched the next tap's first input blocks a second time.
+    constexpr bool UNI = NW <= 4 && A_SLOTS % NW == 0 && (NB % NW == 0 || NB % NW == NW / 2);
+    constexpr int WF = NB / NW, WH = NB % NW ? 1 : 0;   // full and half weight rows (UNI)
+    static_assert(!UNI || D == WF + WH + A_SLOTS / NW, "rows of the uniform layout");
     static_assert(R >= 4 && R <= 6, "ring depth");
     static_assert((R - 3) * D <= 63, "vmcnt is 6 bits");
     // (Round 3, measured and dropped: (i) the AccVGPR form of the MFMAs -- hipcc selects the ArchVGPR form for a kernel whose
@@ -171,6 +180,26 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
         // round 6 it fetched block t * A_SLOTS + A_SLOTS (+ 1) -- the next tap's first blocks, a second time: 12 of a chunk's
         // 93 KiB of DMA on the 256 x 96 tile.)  An index past every range keeps it dead in every tap.
         s_aidx[j] = q < SLOTS ? q - NB : 1 << 20;
+    }
+    // UNI: the lane offset of a weight row carries the row's block (and half) offset, so the scalar offset of every weight
+    // DMA of a tap is the stream position itself
+    unsigned wvq[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) wvq[j] = lane16;
+    if constexpr (UNI) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (j < WF) {
+                s_wsrc[j] = (unsigned)(wave + NW * j) * 1024u;
+            } else if (j < WF + WH) {
+                s_wsrc[j] = (unsigned)(NW * WF + (wave >> 1)) * 1024u + (unsigned)(wave & 1) * 512u;
+            } else {
+                s_wsrc[j] = 0u;
+                s_aidx[j] = wave + NW * (j - WF - WH);
+            }
+            s_wdst[j] = lds0 + ring_base + s_wsrc[j];
+            wvq[j] = lane16 + s_wsrc[j];
+        }
     }
 
     // Two workgroups share a CU so that one's epilogue (two transcendentals per output value: a third of the
@@ -331,6 +360,19 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
                         constexpr int d = f - 2;
                         constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
                         constexpr bool a_tap = t < ATAPS;
+                        if constexpr (UNI) {
+                            if constexpr (d < WF) {
+                                dma16s(wt_rsrc, sgpr(s_wdst[d] + woff_prev), wvq[d], sgpr(wsoff));
+                            } else if constexpr (d < WF + WH) {
+                                dma16s_lo(wt_rsrc, sgpr(s_wdst[d] + woff_prev), wvq[d], sgpr(wsoff));
+                            } else if constexpr (a_tap) {
+                                const int ia = t * A_SLOTS + s_aidx[d];
+                                const bool alive = ia < na_live;
+                                unsigned av = in_off(a_pl, ia, a_cc);
+                                asm volatile("" : "+v"(av));   // computed unconditionally: a branch around it would split the tap's basic block
+                                dma_in(in_rsrc, sgpr(alive ? a_base + ia * 1024 : scratch), alive ? av : OOB, 0u);
+                            }
+                        } else {
                         const unsigned w_lds = s_wdst[d] + woff_prev, w_soff = s_wsrc[d] + wsoff;
                         const int ia = t * A_SLOTS + s_aidx[d];
                         const bool alive = a_tap && ia < na_live;
@@ -349,6 +391,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
                                 asm volatile("" : "+v"(av));   // computed unconditionally: a branch around it would split the tap's basic block
                                 av = (a_tap && alive) ? av : OOB;
                             dma16s(s_rsrc[d], sgpr(isw ? w_lds : a_lds), isw ? wv : av, sgpr(isw ? w_soff : 0u));
+                        }
                         }
                     } else {
                         at_n = a_addr(t == 8 ? abuf_next : abuf, tn);
@@ -404,7 +447,12 @@ __global__ __launch_bounds__(WM* WN * 64, (MREP * NREP > 8 ? 1 : WM * WN == 4 ? 
                 // the MFMAs in place and the compiler sinks them towards the end of the chunk)
                 if constexpr (t == 9 - R) {
                     wsoff = in_tile ? wsoff + wstep : w_tile_next;
-                    wv = in_tile ? wv : (has_next ? lane16 : OOB);
+                    if constexpr (UNI) {
+#pragma unroll
+                        for (int j = 0; j < WF + WH; ++j) wvq[j] = in_tile ? wvq[j] : (has_next ? lane16 + s_wsrc[j] : OOB);
+                    } else {
+                        wv = in_tile ? wv : (has_next ? lane16 : OOB);
+                    }
                 } else {
                     wsoff += wstep;
                 }
@@ -547,6 +595,10 @@ const T32Tile kT32Tiles[] = {
     // whole-row stores for the two-per-CU tiles: rows staged through the input buffer the last chunk is done with
     T32(4, 1, 2, 3, 4, 4, 2, 2),    // 13: tile 10 (256 x 96), where that buffer holds the wave stages (80-wide maps)
     T32(2, 2, 2, 3, 2, 4, 2, 2),    // 14: tile 9 (128 x 192)
+    // THREE two-wave workgroups per CU (round 6): 128 x 96 with the full 64 x 96 wave tile, for launches
+    // whose 256-row tiles are fewer than the chip's workgroup slots (M25600 N288 at 64 images: 300 tiles of 256 x 96 on 512
+    // slots).  20-wide maps only: on 40-wide ones the input ranges leave room for two per CU.
+    T32(2, 1, 2, 3, 2, 4, 0, 3),    // 15: 128 x 96
 #ifdef RMR_T32_PINGPONG
     // 15.. (development builds): the ping-pong form
     { 256, 192, 512, 4, 5, 3, 0, 1, conv_t32pp_kernel<4, 2, 2, 3, 4, 5, 0> },     // 13: 256 x 192

@@ -23,6 +23,15 @@ __device__ __forceinline__ void dma16s(u32x4 rsrc, unsigned lds_addr, unsigned v
                  : "memory");
 }
 
+// the lower half of the wave only: lanes 0..31 move 512 bytes to lds_addr + lane * 16, lanes 32..63 sit the instruction out
+// (two waves share one KiB block: a row of DMA slots that has half as many blocks as the workgroup has waves)
+__device__ __forceinline__ void dma16s_lo(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 exec_hi, 0\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 exec_hi, -1"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
 // the same with the non-temporal hint (streamed once: do not displace what the other tiles re-read from L2)
 __device__ __forceinline__ void dma16s_nt(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
