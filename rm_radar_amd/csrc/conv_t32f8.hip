@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
         s_rsrc[j] = NW * (j + 1) <= NB ? wt_rsrc : NW * j >= NB ? in_rsrc : (s_isw[j] ? wt_rsrc : in_rsrc);
         s_wdst[j] = lds0 + ring_base + q * 1024;
         s_wsrc[j] = (unsigned)q * 1024u;
-        s_aidx[j] = q - NB;
+        s_aidx[j] = q < SLOTS ? q - NB : 1 << 20;   // a surplus slot (D * NW > SLOTS) fetches nothing
     }
 
     // Two workgroups share a CU so that one's epilogue (two transcendentals per output value: a third of the
@@ -204,13 +204,13 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
     __builtin_amdgcn_s_barrier();
 
     constexpr int NM = MREP * NREP;   // MFMAs per K-step
-    int slot = 0;                     // ring slot of the tap being computed
-    int abuf = 0;                     // input buffer of the chunk being computed
-    // the weight stream: slice gw of the tile whose channel-tile offset is w_tile is the next one to fetch
-    unsigned gw = R - 1;
-    unsigned gwoff = (unsigned)(R - 1) * wstep;
-    unsigned w_tile = (unsigned)(n0 / 16) * 1024u;
-    unsigned w_live = 1u;
+    // the K loop's scalar state, as in conv_t32.hip (round 6): byte offsets instead of slot numbers, and the weight stream
+    // crosses into the next tile behind the compile-time tap 9 - R of a tile's last chunk -- no slice counter, no per-tap selects
+    int woff = 0;                               // ring slot of the tap being computed, as a byte offset
+    int woff_prev = (R - 1) * SLOT_BYTES;       // the slot the previous tap left: where this tap's weight DMAs land
+    int abuf = 0;                               // input buffer of the chunk being computed
+    unsigned wsoff = (unsigned)(n0 / 16) * 1024u + (unsigned)(R - 1) * wstep;   // the next slice to fetch
+    unsigned wv = lane16;                       // the weight DMAs' lane offset: OOB once the stream has run past the last tile
 
     for (;;) {
         // ---- this tile and the next one -------------------------------------------------------------
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
 
         // fragments of tap 0: the slice and the range were waited for before the last barrier
         intx8 X[MREP], Xn[MREP], Wf[NREP];   // pixel fragments of this tap and of the next one; weight fragments (rolling)
-        int wcur = wlane + slot * SLOT_BYTES;
+        int wcur = wlane + woff;
         {
             const int at = a_addr(abuf, 0);
 #pragma unroll
@@ -259,16 +259,16 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
             const bool a_live = in_tile || has_next;
             const int a_pl = in_tile ? pl : pln;
             const int a_cc = in_tile ? cc + 1 : 0;
+            const int na_live = a_live ? na : 0;                       // blocks of the range fetched during this chunk
+            const unsigned a_base = lds0 + (unsigned)abuf_next;        // where they land
             // One tap = NM MFMAs of 64 pipe cycles, weight-fragment-major: fragment j serves MFMAs j MREP .. and is
             // re-read for the next tap behind its last one; the next tap's pixel fragments and the DMA issue ride
             // behind the others.  Everything read for tap t + 1 during tap t was waited for one tap ago.
             const auto tap = [&](auto T) {
                 constexpr int t = decltype(T)::value;
                 constexpr int tn = (t + 1) % 9;
-                const int slot_w = slot == 0 ? R - 1 : slot - 1;
-                const int slot_n = slot + 1 == R ? 0 : slot + 1;
-                const int wnext = wlane + slot_n * SLOT_BYTES;
-                const unsigned wv = w_live ? lane16 : OOB;
+                const int woff_n = woff + SLOT_BYTES == R * SLOT_BYTES ? 0 : woff + SLOT_BYTES;
+                const int wnext = wlane + woff_n;
                 __builtin_amdgcn_s_barrier();
                 static_for<0, NM>([&](auto Kc) {
                     constexpr int k = decltype(Kc)::value;
@@ -291,10 +291,10 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
                         if constexpr ((NM > D + 1 ? 1 + d : d * NM / D) == k) {
                             constexpr bool all_w = NW * (d + 1) <= NB, all_a = NW * d >= NB;
                             constexpr bool a_tap = t < ATAPS;
-                            const unsigned w_lds = s_wdst[d] + slot_w * SLOT_BYTES, w_soff = s_wsrc[d] + w_tile + gwoff;
+                            const unsigned w_lds = s_wdst[d] + woff_prev, w_soff = s_wsrc[d] + wsoff;
                             const int ia = t * A_SLOTS + s_aidx[d];
-                            const bool alive = a_tap && a_live && ia < na;
-                            const unsigned a_lds = alive ? lds0 + abuf_next + ia * 1024 : scratch;
+                            const bool alive = a_tap && ia < na_live;
+                            const unsigned a_lds = alive ? a_base + ia * 1024 : scratch;
                             if constexpr (all_w) {
                                 dma16s(wt_rsrc, sgpr(w_lds), wv, sgpr(w_soff));
                             } else if constexpr (all_a) {
@@ -315,7 +315,8 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
                     if constexpr (k == NM - 1) {
                         constexpr int t2 = (t + 2) % 9;
                         at_n = a_addr(t + 2 >= 9 ? abuf_next : abuf, t2);
-                        slot = slot_n;
+                        woff_prev = woff;
+                        woff = woff_n;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -332,11 +333,12 @@ __global__ __launch_bounds__(WM* WN * 64, WPC * WM * WN / 4) void conv_t32f8_ker
                 for (int i = 0; i < MREP; ++i) X[i] = Xn[i];   // renamed away inside the unrolled chunk
                 // (selects, not a branch: a tap must stay one basic block, or the scheduling pins above do not hold
                 // the MFMAs in place and the compiler sinks them towards the end of the chunk)
-                const unsigned wrap = 0u - (unsigned)(gw + 1 == (unsigned)total);   // all ones behind the tile's last slice
-                gw = (gw + 1) & ~wrap;
-                gwoff = (gwoff + wstep) & ~wrap;
-                w_tile ^= (w_tile ^ w_tile_next) & wrap;
-                w_live ^= (w_live ^ (unsigned)has_next) & wrap;
+                if constexpr (t == 9 - R) {
+                    wsoff = in_tile ? wsoff + wstep : w_tile_next;
+                    wv = in_tile ? wv : (has_next ? lane16 : OOB);
+                } else {
+                    wsoff += wstep;
+                }
             };
             tap(tap_c<0>{});
             tap(tap_c<1>{});

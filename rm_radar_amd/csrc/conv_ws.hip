@@ -368,7 +368,12 @@ void conv_ws_kernel(const ConvArgs a, const int strip_rows) {
 // vmcnt discipline (loads and stores retire in order): the shortcut loads of a tile are issued after that tile loop's two
 // stores and before its row DMAs, and are waited for one tile loop later with vmcnt(row DMAs issued since).
 constexpr int WP_SLOTS = 8;
-constexpr int WP_STAGE = 3072;   // per wave: one tile of 16 pixels x 48 channels as f32 (shortcut) or f16
+// The stage's pixel pitch is NOT the pixel's size: at 96 bytes (f16) pixels p and p + 8 start on the same bank, at 192 bytes
+// (f32) pixels p and p + 4 -- the sixteen pixels of a stage write met on two / four bank groups, 45 % of the kernel's LDS cycles
+// were bank conflicts (profiles/r04_conv_ws_pmc.txt).  112 = 7 x 16 and 208 = 13 x 16 bytes put the sixteen pixels of a
+// ds_write_b64 / ds_write_b128 pass on sixteen different bank groups and keep the drain's 16-byte reads aligned.
+constexpr int WP_PITCH16 = 112, WP_PITCH32 = 208;
+constexpr int WP_STAGE = 16 * WP_PITCH32;   // per wave: one tile of 16 pixels x 48 channels as f32 (shortcut) or f16
 constexpr int wp_lds(int nw) { return WP_SLOTS * WS_ROW + nw * WP_STAGE + 1024 + 256; }  // + idle-DMA KiB + bias
 
 __device__ __forceinline__ u32x4 ld16_asm(u32x4 rsrc, unsigned voff) {
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
     const unsigned lane_off = (unsigned)(frow * WS_PIX + kg * 16 + (xh * 80 + t0 * 16) * WS_PIX);
     const int px = lane & 15, cq = (lane >> 4) * 4;
     // MFMA layout -> stage (pixel-major; f32 when a shortcut is added at the drain, else f16)
-    unsigned char* const sw = stage_p + (RES ? px * 192 + cq * 4 : px * 96 + cq * 2);
+    unsigned char* const sw = stage_p + (RES ? px * WP_PITCH32 + cq * 4 : px * WP_PITCH16 + cq * 2);
     // drain layout: chunk c = 16 bytes of output = 8 channels; six chunks per pixel; lane l drains chunks l and 64 + l (l < 32)
     // (pixel, part) of the two chunks packed into ONE register: the byte offsets into the stage, the output and the
     // shortcut tensor are two multiply-adds away when they are needed (registers are what limits two waves per SIMD)
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void conv_wsp_kernel(const ConvArgs a
     const auto cp = [&](int c) { return (pqv() >> (c ? 8 : 0)) & 15u; };
     const auto cqq = [&](int c) { return (pqv() >> (c ? 12 : 4)) & 15u; };
     const auto dead = [&](int c) { return c ? 0u - ((pqv() >> 16) & 1u) : 0u; };   // all ones: lanes 32-63 have no second chunk
-    const auto stage_rd = [&](int c) { return stage_p + (RES ? cp(c) * 192u + cqq(c) * 32u : cp(c) * 96u + cqq(c) * 16u); };
+    const auto stage_rd = [&](int c) { return stage_p + (RES ? cp(c) * (unsigned)WP_PITCH32 + cqq(c) * 32u : cp(c) * (unsigned)WP_PITCH16 + cqq(c) * 16u); };
     const unsigned out_pitch2 = (unsigned)a.out_cs * 2u, out_co2 = (unsigned)a.out_co * 2u;
     const unsigned res_pitch2 = (unsigned)a.res_cs * 2u, res_co2 = (unsigned)a.res_co * 2u;
     const auto out_off = [&](int c) { return cp(c) * out_pitch2 + out_co2 + cqq(c) * 16u; };
