@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-R, TAG = "r05", "v1"
+R, TAG = "r06", "v1"
 BEGIN, END = "<!-- numbers:begin (tools/design_numbers.py --write) -->", "<!-- numbers:end -->"
 
 
@@ -48,7 +48,7 @@ def rows():
         add("p50 / p99 per frame at batch 1 (host inputs)", f"{b['p50_ms_batch1']:.3f} / {b['p99_ms_batch1']:.3f} ms ({b.get('latency_kernel_plan')})", src)
         r = b["roofline"]
         tm = r.get("traffic_mix") or {}
-        add("dominant kernel (conv_t32 g10)", f"{r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of 2500; {r['launches_per_step']:.0f} launches per step, "
+        add("dominant kernel (" + str(r.get("kernel", ""))[:60] + " ...)", f"{r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of 2500; {r['launches_per_step']:.0f} launches per step, "
             f"{r['avg_launch_ms'] * 1e3:.1f} us per launch", src)
         if r.get("traffic"):
             add("its HBM-side traffic (PMC)", f"{r['traffic'] / 1e6:.1f} MB per launch vs {r['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic = "
@@ -87,40 +87,50 @@ def rows():
             f"(source hash {d['source_hash']})", f"{R}_pmc_conv_traffic.json")
     else:
         add("PMC traffic", None, f"{R}_pmc_conv_traffic.json")
-    ys = text(f"{R}_yardstick.txt")
+    # ---- round 6's own experiments
+    ab = text(f"{R}_ab_t32_scalar_state.txt")
+    m = ab and re.findall(r"^(A|B): .*?: ([\d.]+) frames/s over .*?steady state ([\d.]+) .*?all conv launches ([\d.]+);", ab, re.M)
+    if m and len(m) >= 2:
+        A, B = next(x for x in m if x[0] == "A"), next(x for x in m if x[0] == "B")
+        add("same box: conv_t32 as of round 5 (A) against the round-6 K loop (B), the bench step", f"frames/s {float(A[1]):.0f} -> {float(B[1]):.0f} (steady state "
+            f"{float(A[2]):.0f} -> {float(B[2]):.0f}); all convolution launches {float(A[3]):.0f} -> {float(B[3]):.0f} TFLOP/s", f"{R}_ab_t32_scalar_state.txt")
+    else:
+        add("same-box A/B of the conv_t32 K loop", None, f"{R}_ab_t32_scalar_state.txt")
+    tw = text(f"{R}_tile15_and_wsp_pitch.txt")
+    if tw:
+        us = lambda pat: [float(v) for v in re.findall(pat, tw)]
+        t810, t815, sb = us(r"res0 kernel 810:\s+([\d.]+) us"), us(r"res0 kernel 815:\s+([\d.]+) us"), us(r"res0 kernel 100052:\s+([\d.]+) us")
+        old, newp = us(r"^96/192 B: .*res0 kernel 312:\s+([\d.]+) us"), us(r"^112/208 B: .*res0 kernel 312:\s+([\d.]+) us")
+        old = [float(v) for v in re.findall(r"96/192 B: \S+ \S+ \S+ k3 s1 res0 kernel 312:\s+([\d.]+) us", tw)]
+        newp = [float(v) for v in re.findall(r"112/208 B: \S+ \S+ \S+ k3 s1 res0 kernel 312:\s+([\d.]+) us", tw)]
+        add("tile 15 (128 x 96, three two-wave workgroups per CU) on M25600 N288 K2592", f"{min(t815):.1f} us against {min(t810):.1f} (tile 10) and {min(sb):.1f} "
+            f"(conv_sb 128 x 96): no gain, stays in the tuner's pool" if t810 and t815 and sb else None, f"{R}_tile15_and_wsp_pitch.txt")
+        add("conv_wsp (w12) with the conflict-free stage pitch (112 / 208 B) against the pixel's own (96 / 192 B)", f"{min(newp):.1f} us against {min(old):.1f}: "
+            f"the stage's bank conflicts are not what the kernel waits for" if old and newp else None, f"{R}_tile15_and_wsp_pitch.txt")
+    else:
+        add("tile 15 / conv_wsp pitch", None, f"{R}_tile15_and_wsp_pitch.txt")
+    c1 = jline(f"{R}_bench_config1.json")
+    if c1:
+        sp = c1["stage_split_ms_per_frame"]
+        h2d = next(v for k, v in sp.items() if k.startswith("staging"))
+        add("configs[1]: batch 1 on the reference sample's 2592 x 2048 frames from host memory", f"p50 {c1['p50_ms_batch1']:.3f} / p99 {c1['p99_ms_batch1']:.3f} ms over "
+            f"{c1['latency_sample']['timed_frames']} frames; staging + H2D {h2d:.3f} ms ({100 * sp['h2d_fraction_of_frame']:.0f} % of the frame; inputs in HBM: p50 "
+            f"{c1['inputs_resident_in_hbm']['p50_ms']:.3f} ms); parity checked: {c1.get('parity_checked')}, network checked: {(c1.get('parity') or {}).get('network_checked')}",
+            f"{R}_bench_config1.json")
+    else:
+        add("configs[1]", None, f"{R}_bench_config1.json")
+    for k in (0, 20):
+        bk = jline(f"{R}_bench_crops{k}_{TAG}.json")
+        add(f"K = {k} crops per frame (SURVEY 8d bound)", f"{bk['value']:.0f} frames/s, parity checked: {bk.get('parity_checked')}" if bk else None, f"{R}_bench_crops{k}_{TAG}.json")
+    # ---- carried from round 5 (one-off studies, not repeated: the kernels they compare against only got faster)
+    ys = text("r05_yardstick.txt")
     if ys:
         lines = [l for l in ys.splitlines() if l.startswith("conv ")]
         ahead = sum("ahead of both" in l for l in lines)
         within = sum("within 10" in l for l in lines)
         behind = sum("vendor ahead" in l for l in lines)
-        add("vendor yardstick (hipBLASLt GEMM / MIOpen conv2d, same box)", f"{len(lines)} layers: this engine ahead on {ahead}, within 10 % on {within}, behind on {behind}",
-            f"{R}_yardstick.txt")
-    else:
-        add("vendor yardstick", None, f"{R}_yardstick.txt")
-    gb = text(f"{R}_grid_barrier.txt")
-    m = gb and re.search(r"grid 150 x 448 threads, 16384 B per workgroup: per phase\s+flat barrier\s+([\d.]+) us\s+xcd barrier\s+([\d.]+) us\s+separate launches\s+([\d.]+) us", gb)
-    add("a phase of 150 workgroups publishing 16 KB each: in-launch grid barrier vs launches", f"flat {m.group(1)} us, XCD-hierarchical {m.group(2)} us, "
-        f"separate launches {m.group(3)} us" if m else None, f"{R}_grid_barrier.txt")
-    cp = text(f"{R}_chain_prototype.txt")
-    m = cp and re.findall(r"^(.+?)\s+grid\s+\d+ x\s+\d+ threads: three launches\s+([\d.]+) us\s+one launch with two grid barriers\s+([\d.]+) us\s+\(\s*([+-][\d.]+) %\)\s+outputs (\S+)", cp, re.M)
-    if m:
-        lo, hi = min(float(x[3]) for x in m), max(float(x[3]) for x in m)
-        k3 = next((x for x in m if "32 x 32, K over three waves" in x[0]), m[0])
-        add("the 3-op prototype (a C2f bottleneck chain at 20 x 20): one launch with two grid barriers against its three launches",
-            f"{lo:+.1f} ... {hi:+.1f} % over {len(m)} tile shapes (slower everywhere; the product's 32 x 32 / three-wave form: {k3[1]} -> {k3[2]} us), "
-            f"outputs {'bit-identical' if all(x[4].startswith('bit-identical') for x in m) else 'DIFFER'}", f"{R}_chain_prototype.txt")
-    else:
-        add("the 3-op prototype", None, f"{R}_chain_prototype.txt")
-    ab = text(f"{R}_ab_r04_vs_{R}.txt")
-    rows_ab = ab and [l.split() for l in ab.splitlines() if l.startswith(("r04_", f"{R}_"))]
-    if rows_ab:
-        def mean(tag, col):
-            v = [float(r[col]) for r in rows_ab if r[0].startswith(tag)]
-            return sum(v) / len(v)
-        add("same box, alternating runs: the round-4 tree against this one (each under its committed plan)",
-            f"frames/s {mean('r04', 1):.0f} -> {mean(R, 1):.0f}; p50 {mean('r04', 3):.3f} -> {mean(R, 3):.3f} ms; p99 {mean('r04', 4):.3f} -> {mean(R, 4):.3f} ms", f"{R}_ab_r04_vs_{R}.txt")
-    else:
-        add("same-box A/B against the round-4 tree", None, f"{R}_ab_r04_vs_{R}.txt")
+        add("vendor yardstick of round 5 (hipBLASLt GEMM / MIOpen conv2d, same box)", f"{len(lines)} layers: this engine ahead on {ahead}, within 10 % on {within}, behind on {behind}",
+            "r05_yardstick.txt")
     f8 = jline(f"{R}_bench_config4_fp8_{TAG}.json")
     add("configs[4] (fp8 plan, 256 frames per step)", f"{f8['value']:.0f} frames/s, parity checked: {f8.get('parity_checked')}" if f8 else None, f"{R}_bench_config4_fp8_{TAG}.json")
     c3 = jline(f"{R}_bench_config3_{TAG}.json")

@@ -5,7 +5,7 @@
 # usage: bash tools/round_profile.sh <tag> [round]
 set -u
 TAG=${1:-v1}
-R=${2:-r04}
+R=${2:-r06}
 export TMPDIR=/tmp
 OUT=gpurun_out/round
 rm -rf $OUT; mkdir -p $OUT
@@ -14,7 +14,9 @@ SCMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-latency --no-p
 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $SCMD > $OUT/${R}_bench_b64_${TAG}_under_rocprof.json 2> $OUT/stats.log
 python tools/rocpd_summary.py $(find $OUT/stats -name "*.db" | head -1) > $OUT/${R}_bench_b64_kernel_stats_${TAG}.txt
 rm -rf $OUT/stats
-python bench.py --steps 5 --warmup 2 > $OUT/${R}_bench_b64_${TAG}.json 2> $OUT/bench.log
+# the driver's own command form: 20 steps behind 5 warm-up steps, every leg
+python bench.py --steps 20 --warmup 5 > $OUT/${R}_bench_b64_${TAG}.json 2> $OUT/bench.log
+cp $OUT/${R}_bench_b64_${TAG}.json $OUT/${R}_bench_default_final.json
 for spec in "64 12 " "256 12 _b256" "4 12 _b4" "1 1 _b1"; do
     set -- $spec
     python tools/layer_profile.py $1 $2 > $OUT/${R}_layer_profile${3:-}_${TAG}.txt 2>&1

@@ -3,7 +3,7 @@
 # one layer, the fp8 plan's profile and bench lines, configs[3].  usage: bash tools/round_profile_extra.sh <tag> [round]
 set -u
 TAG=${1:-v1}
-R=${2:-r04}
+R=${2:-r06}
 export TMPDIR=/tmp
 OUT=gpurun_out/round
 mkdir -p $OUT
@@ -40,4 +40,9 @@ RMR_FP8=1 python tools/layer_profile.py 256 12 > $OUT/${R}_layer_profile_b256_fp
 python bench.py --config 4 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/${R}_bench_config4_fp8_${TAG}.json 2> $OUT/bench_fp8.log
 python bench.py --config 3 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_config3_${TAG}.json 2>> $OUT/bench_fp8.log
 python bench.py --dtype fp8 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_b64_fp8_${TAG}.json 2>> $OUT/bench_fp8.log
+# configs[1]: batch 1 on the reference sample's 2592 x 2048 frames + 10 k-point clouds from host memory
+python bench.py --config 1 > $OUT/${R}_bench_config1.json 2>> $OUT/bench_fp8.log
+# the bounds SURVEY 8d asks for beside the K = 4 headline: K = 0 (car stage only) and K = 20 (kMaxBatchSize)
+python bench.py --crops 0 --steps 10 --warmup 2 --no-cpu-baseline --no-latency > $OUT/${R}_bench_crops0_${TAG}.json 2>> $OUT/bench_fp8.log
+python bench.py --crops 20 --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/${R}_bench_crops20_${TAG}.json 2>> $OUT/bench_fp8.log
 tail -c 700 $OUT/${R}_bench_config4_fp8_${TAG}.json
