@@ -59,7 +59,8 @@ KERNEL_OF_TAG = {"g": "conv_t32_kernel (csrc/conv_t32.hip)", "m": "conv_g32_kern
                  "v": "conv_ws_s2_kernel (csrc/conv_ws_s2.hip)", "d": "conv_dma_kernel (csrc/conv_dma.hip)",
                  "t": "conv_igemm_kernel (csrc/conv_igemm.hip)", "h": "conv_halo_kernel (csrc/conv_halo.hip)",
                  "x": "conv_direct_kernel (csrc/conv_direct.hip)", "f": "conv_t32f8_kernel (csrc/conv_t32f8.hip)",
-                 "s": "conv_stem_kernel (csrc/conv_stem.hip)", "b": "conv_wsf_kernel (csrc/conv_ws.hip: a fused C2f bottleneck)"}
+                 "s": "conv_stem_kernel (csrc/conv_stem.hip)", "b": "conv_wsf_kernel (csrc/conv_ws.hip: a fused C2f bottleneck)",
+                 "y": "head_fused_kernel (csrc/net_ops.hip: the Detect head's last 1x1 convolutions + DFL decode)"}
 
 
 def instantiation_of(layer_name):

@@ -29,4 +29,22 @@ void launch_head_decode(DeviceCtx& ctx, hipStream_t s, const float* box, const f
 void launch_head_decode3(DeviceCtx& ctx, hipStream_t s, int scales, const float* const* box, const float* const* cls, int cls_cs, int nc,
                          float* out, int N, const int* H, const int* W, const int* stride, const int* a_off, int a_total);
 
+// The Detect head's LAST convolutions and its decode in one launch (round 6): per scale the 1x1 convolution 64 -> 64 of the box
+// branch (the 4 x 16 distribution logits) and the 1x1 convolution c3 -> nc of the class branch run on MFMAs straight from the
+// f16 feature rows (a wave per 16 anchors, both filters in registers), the DFL softmax expectation + dist2bbox + sigmoid run
+// on the accumulators, and only the [N][4 + nc][A_total] f32 tensor is written.  The f32 logit tensors (320 B per anchor
+// written and read back) and six of the tiniest GEMMs of the network (N = 64 / 16: 44-95 TFLOP/s) disappear.
+struct HeadFusedScale {
+    const __half* hb;      // box-branch features [N][H*W] rows of cs_b halves, 64 channels from co_b
+    const __half* hc;      // class-branch features, kc channels from co_c
+    const __half* wb;      // [64][kp_b] f16, K-inner
+    const __half* wc;      // [16 ceil(nc / 16)][kp_c]
+    const float* bb;       // 64
+    const float* bc;       // 16 ceil(nc / 16)
+    int H, W, stride, a_off, cs_b, co_b, cs_c, co_c, kp_b, kp_c, kc;
+};
+// kc in {64, 96, 128, 192, 256}, nc <= 16; false: the caller keeps the separate convolutions + launch_head_decode3
+bool head_fused_supported(int kb, int kc, int nc);
+void launch_head_fused(DeviceCtx& ctx, hipStream_t s, int scales, const HeadFusedScale* sc, int nc, float* out, int N, int a_total);
+
 }  // namespace rmr

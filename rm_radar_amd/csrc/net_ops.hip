@@ -3,6 +3,11 @@
 #include "net_ops.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
 
 namespace rmr {
 
@@ -212,6 +217,143 @@ void launch_head_decode3(DeviceCtx& ctx, hipStream_t s, int scales, const float*
     }
     ProfScope ps(ctx.prof, s, "head_decode", 0, (double)total * (64 + cls_cs + 4 + nc) * 4);
     head_decode3_kernel<<<dim3((unsigned)((most + 255) / 256), scales), 256, 0, s>>>(hs, cls_cs, nc, out, N, a_total);
+    RMR_HIP(hipGetLastError());
+}
+
+// ---- the fused form: last 1x1 convolutions + decode --------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+struct HeadFusedArgs {
+    HeadFusedScale s[3];
+};
+
+// sum / max over the four lanes that share an anchor (lanes a, a + 16, a + 32, a + 48)
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+
+// KC = class-branch channels.  A workgroup of four waves takes 256 consecutive anchors of one scale; a wave takes four tiles
+// of 16.  MFMA operands swapped as everywhere in the engine (D = W . X): lane (a = lane & 15, kg = lane >> 4) ends up with
+// logits 4 kg .. 4 kg + 3 of every 16-channel tile for anchor a -- four bins of each side of the box distribution, four classes.
+template <int KC>
+__global__ __launch_bounds__(256) void head_fused_kernel(const HeadFusedArgs hs, int nc, float* __restrict__ out, int N, int a_total) {
+    const HeadFusedScale S = hs.s[blockIdx.y];
+    const int hw = S.H * S.W;
+    const long total = (long)N * hw;
+    const long wg0 = (long)blockIdx.x * 256;
+    if (wg0 >= total) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, kg = lane >> 4;
+    // both filters as A fragments, for the life of the workgroup
+    half8 wbf[4][2], wcf[KC / 32];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wbf[j][ks] = *(const half8*)((const _Float16*)S.wb + (size_t)(j * 16 + frow) * S.kp_b + ks * 32 + kg * 8);
+#pragma unroll
+    for (int ks = 0; ks < KC / 32; ++ks) wcf[ks] = *(const half8*)((const _Float16*)S.wc + (size_t)frow * S.kp_c + ks * 32 + kg * 8);
+    float4 bbv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bbv[j] = *(const float4*)(S.bb + j * 16 + kg * 4);
+    const float4 bcv = *(const float4*)(S.bc + kg * 4);
+    const float st = (float)S.stride;
+
+#pragma unroll 2
+    for (int t = 0; t < 4; ++t) {
+        const long idx0 = wg0 + (wave * 4 + t) * 16;
+        if (idx0 >= total) break;   // wave-uniform
+        const long idx = idx0 + frow;
+        const bool live = idx < total;
+        const long ic = live ? idx : total - 1;
+        const _Float16* const pb = (const _Float16*)S.hb + ic * S.cs_b + S.co_b + kg * 8;
+        const _Float16* const pc = (const _Float16*)S.hc + ic * S.cs_c + S.co_c + kg * 8;
+        half8 xb[2], xc[KC / 32];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xb[ks] = *(const half8*)(pb + ks * 32);
+#pragma unroll
+        for (int ks = 0; ks < KC / 32; ++ks) xc[ks] = *(const half8*)(pc + ks * 32);
+        floatx4 box[4], cls = {bcv.x, bcv.y, bcv.z, bcv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            box[j] = floatx4{bbv[j].x, bbv[j].y, bbv[j].z, bbv[j].w};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) box[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wbf[j][ks], xb[ks], box[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KC / 32; ++ks) cls = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcf[ks], xc[ks], cls, 0, 0, 0);
+        // DFL: side j = channel tile j; this lane holds bins 4 kg .. 4 kg + 3 of it
+        float dist[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mx = quad_max(fmaxf(fmaxf(box[j][0], box[j][1]), fmaxf(box[j][2], box[j][3])));
+            float se = 0.f, sw = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ex = __expf(box[j][e] - mx);
+                se += ex;
+                sw += ex * (float)(kg * 4 + e);
+            }
+            dist[j] = quad_sum(sw) / quad_sum(se);
+        }
+        const int n = (int)(ic / hw), a = (int)(ic % hw);
+        const float ax = (float)(a % S.W) + 0.5f, ay = (float)(a / S.W) + 0.5f;
+        const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+        float* const o = out + (long)n * (4 + nc) * a_total + S.a_off + a;
+        if (live) {
+            // the four lanes of an anchor write one box component each (16 consecutive anchors per component: 64-byte runs)
+            const float comp = kg == 0 ? (x1 + x2) * 0.5f * st : kg == 1 ? (y1 + y2) * 0.5f * st : kg == 2 ? (x2 - x1) * st : (y2 - y1) * st;
+            o[(long)kg * a_total] = comp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = kg * 4 + e;
+                if (c < nc) o[(long)(4 + c) * a_total] = 1.0f / (1.0f + __expf(-cls[e]));
+            }
+        }
+    }
+}
+
+bool head_fused_supported(int kb, int kc, int nc) {
+    return kb == 64 && nc >= 1 && nc <= 16 && (kc == 64 || kc == 96 || kc == 128 || kc == 192 || kc == 256);
+}
+
+void launch_head_fused(DeviceCtx& ctx, hipStream_t s, int scales, const HeadFusedScale* sc, int nc, float* out, int N, int a_total) {
+    if (scales < 1 || scales > 3) fail(RMR_ERR_LOGIC, "head_fused: %d scales", scales);
+    HeadFusedArgs hs{};
+    long most = 0, total = 0;
+    double flops = 0;
+    for (int i = 0; i < scales; ++i) {
+        if (sc[i].kc != sc[0].kc || !head_fused_supported(64, sc[i].kc, nc) || sc[i].kp_b < 64 || sc[i].kp_c < sc[i].kc || (sc[i].cs_b | sc[i].co_b | sc[i].cs_c | sc[i].co_c) & 7)
+            fail(RMR_ERR_LOGIC, "head_fused: scale %d does not fit the kernel (kc %d, pitches %d / %d)", i, sc[i].kc, sc[i].cs_b, sc[i].cs_c);
+        hs.s[i] = sc[i];
+        const long m = (long)N * sc[i].H * sc[i].W;
+        most = std::max(most, m);
+        total += m;
+        flops += 2.0 * m * (64.0 * 64 + (double)nc * sc[i].kc);
+    }
+    // per-layer profile name in the convolutions' form (bench.py groups by the trailing tag: y = this kernel)
+    static const bool per_layer = std::getenv("RMR_PROFILE_LAYERS") != nullptr;
+    static std::mutex name_mu;
+    static std::map<std::string, std::string> names;
+    const char* pname = "conv_igemm_f16";
+    if (per_layer && ctx.prof.on) {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "conv n%d M%ld N%d K%d k1 s1 y0", N, total, 64 + nc, 64 + sc[0].kc);
+        std::lock_guard<std::mutex> lk(name_mu);
+        pname = names.emplace(buf, buf).first->second.c_str();
+    }
+    ProfScope ps(ctx.prof, s, pname, flops, (double)total * ((64 + sc[0].kc) * 2.0 + (4 + nc) * 4.0));
+    const dim3 grid((unsigned)((most + 255) / 256), scales);
+    switch (sc[0].kc) {
+        case 64: head_fused_kernel<64><<<grid, 256, 0, s>>>(hs, nc, out, N, a_total); break;
+        case 96: head_fused_kernel<96><<<grid, 256, 0, s>>>(hs, nc, out, N, a_total); break;
+        case 128: head_fused_kernel<128><<<grid, 256, 0, s>>>(hs, nc, out, N, a_total); break;
+        case 192: head_fused_kernel<192><<<grid, 256, 0, s>>>(hs, nc, out, N, a_total); break;
+        default: head_fused_kernel<256><<<grid, 256, 0, s>>>(hs, nc, out, N, a_total); break;
+    }
     RMR_HIP(hipGetLastError());
 }
 

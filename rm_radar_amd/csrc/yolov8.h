@@ -111,6 +111,10 @@ class Yolov8 {
         // OP_HEAD
         View box, cls;
         int head_stride = 0, a_off = 0;
+        // ... in the fused form (head_fused_kernel: the last 1x1 convolutions of both branches + the decode): the two
+        // convolutions (indices into convs_) and the feature views they read; box / cls are not allocated
+        int box_conv = -1, cls_conv = -1;
+        View hb, hc;
     };
 
     View alloc(int h, int w, int c, bool f32 = false);

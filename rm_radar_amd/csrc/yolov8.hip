@@ -526,8 +526,13 @@ void Yolov8::compact_arenas() {
                 view(op.out, false);
                 break;
             case OP_HEAD:
-                view(op.box, true);
-                view(op.cls, true);
+                if (op.box_conv >= 0) {
+                    view(op.hb, false);
+                    view(op.hc, false);
+                } else {
+                    view(op.box, true);
+                    view(op.cls, true);
+                }
                 break;
         }
     }
@@ -575,6 +580,8 @@ void Yolov8::compact_arenas() {
         move(op.pre, true);
         move(op.box, true);
         move(op.cls, true);
+        move(op.hb, false);
+        move(op.hc, false);
         if (op.fp8 || op.kind == OP_QUANT) move8(op.q_off);
         if (op.q_out) move8(op.q_out_off);
     }
@@ -740,11 +747,23 @@ Yolov8::Yolov8(DeviceCtx& ctx, const std::string& pack_path, int expect_nc, int 
     for (int i = 0; i < 3; ++i) {
         const View& f = feats[i];
         const std::string b = "model.22.cv2." + std::to_string(i), c = "model.22.cv3." + std::to_string(i);
-        hs[i].box = alloc(f.h, f.w, 64, true), hs[i].cls = alloc(f.h, f.w, cls_pad, true);
-        conv(add_conv_weights(p, b + ".2", 0), hs[i].hb, hs[i].box, 1, 0, nullptr, true);
-        conv(add_conv_weights(p, c + ".2", 0), hs[i].hc, hs[i].cls, 1, 0, nullptr, true);
+        // RMR_FUSE_HEAD=0: the last 1x1 convolutions as launches of their own into f32 logit tensors + the decode pass over them
+        // (rounds 1-5); default: one launch does all three (net_ops.hip head_fused_kernel), the logit tensors do not exist
+        const bool fuse_head = !(std::getenv("RMR_FUSE_HEAD") && atoi(std::getenv("RMR_FUSE_HEAD")) == 0) &&
+                               head_fused_supported(hs[i].c2d, hs[i].c3d, nc_) && cls_pad == 16;
         Op op{};
         op.kind = OP_HEAD;
+        if (fuse_head) {
+            op.box_conv = add_conv_weights(p, b + ".2", 0);
+            op.cls_conv = add_conv_weights(p, c + ".2", 0);
+            op.hb = hs[i].hb, op.hc = hs[i].hc;
+            for (int widx : {op.box_conv, op.cls_conv})   // the FLOPs conv() would have declared
+                flops_ += 2.0 * f.h * f.w * (double)convs_[widx].cout * convs_[widx].cin;
+        } else {
+            hs[i].box = alloc(f.h, f.w, 64, true), hs[i].cls = alloc(f.h, f.w, cls_pad, true);
+            conv(add_conv_weights(p, b + ".2", 0), hs[i].hb, hs[i].box, 1, 0, nullptr, true);
+            conv(add_conv_weights(p, c + ".2", 0), hs[i].hc, hs[i].cls, 1, 0, nullptr, true);
+        }
         op.box = hs[i].box;
         op.cls = hs[i].cls;
         op.head_stride = strides[i];
@@ -1081,6 +1100,7 @@ unsigned long long Yolov8::plan_signature() const {
     for (const Op& op : ops_) {
         mix(op.kind), mix(op.in.h), mix(op.in.w), mix(op.in.c), mix(op.out.c), mix(op.stride), mix(op.pre.c), mix(op.res.c), mix(op.in_slab_c), mix(op.out_slab_c), mix(op.in.cs), mix(op.out.cs), mix(op.fp8), mix(op.q_pitch), mix(op.q_out), mix(op.q_only), mix(op.group);
         if (op.kind == OP_CONV) mix(convs_[op.conv].K), mix(convs_[op.conv].cout_pad);
+        if (op.kind == OP_HEAD) mix(op.box_conv >= 0);
     }
     return h;
 }
@@ -1446,7 +1466,21 @@ void Yolov8::run_op(hipStream_t s, int op_index, int n, size_t img0) {
                 if (len == 3 || ops_[i].cls.cs != ops_[lead].cls.cs) lead = i, len = 0;
                 ++len;
             }
-            if (lead != op_index) break;
+            if (lead != op_index && op.box_conv < 0) break;
+            if (op.box_conv >= 0) {
+                // fused form: the first OP_HEAD of the stretch launches for all its scales (same class-branch width by construction)
+                if (op_index != b) break;
+                HeadFusedScale sc[3];
+                int k = 0;
+                for (int i = op_index; i < (int)ops_.size() && k < 3 && ops_[i].kind == OP_HEAD && ops_[i].box_conv >= 0; ++i, ++k) {
+                    const Op& o = ops_[i];
+                    const ConvW &wb = convs_[o.box_conv], &wc = convs_[o.cls_conv];
+                    sc[k] = HeadFusedScale{hptr(o.hb), hptr(o.hc), wb.w.p, wc.w.p, wb.b.p, wc.b.p, o.in.h, o.in.w, o.head_stride, o.a_off,
+                                           o.hb.cs, o.hb.co, o.hc.cs, o.hc.co, wb.Kp, wc.Kp, wc.cin};
+                }
+                launch_head_fused(ctx_, s, k, sc, nc_, output_.p + img0 * (size_t)(4 + nc_) * anchors_, n, anchors_);
+                break;
+            }
             const float *box[3], *cls[3];
             int H[3], W[3], st[3], off[3], k = 0;
             for (int i = op_index; i < (int)ops_.size() && k < 3 && ops_[i].kind == OP_HEAD && ops_[i].cls.cs == op.cls.cs; ++i, ++k) {

@@ -329,6 +329,40 @@ def test_upsample_folded_into_the_next_1x1_equals_the_upsample_kernel(rmr, packs
     assert not np.array_equal(out[0], out[1])  # the two plans really are different programs
 
 
+@pytest.mark.parametrize("which,nc,n", [("armor", 12, 3), ("car", 1, 3), ("armor", 12, 70)])
+def test_fused_head_equals_the_last_convolutions_and_the_decode_pass(rmr, packs, refs, images, oracle, monkeypatch, tmp_path, which, nc, n):
+    """Round 6: the Detect head's last 1x1 convolutions (64 -> 64 box logits, 192 -> nc class logits per scale) and the DFL /
+    dist2bbox / sigmoid decode run as ONE launch on the f16 feature rows (net_ops.hip head_fused_kernel); RMR_FUSE_HEAD=0 keeps
+    the six small GEMMs into f32 logit tensors and the decode pass over them (what TensorRT's engine holds as six Conv nodes
+    and the DFL subgraph: src/detect/detector.h:122).  Same features, same weights, f32 throughout: the two programs differ
+    only in the order in which 64 / 192 products are summed per logit and 16 exponentials per side -- a few f32 ulps of a
+    logit, i.e. boxes within 1e-3 px and scores within 1e-5 of each other (batch 70: every tile position of a workgroup, a
+    ragged last workgroup per scale), and both on the oracle."""
+    import shutil
+    src = packs[0 if which == "car" else 1]
+    pack = shutil.copyfile(src, str(tmp_path / "fused_head.rmrw"))   # its own tuning cache: the two plans have different op lists
+    batch = [images[i % 3] for i in range(n)]
+    blobs = np.stack([oracle.preprocess(im)[0] for im in images])
+    want = refs[which][1].forward(blobs)
+    out = []
+    monkeypatch.setenv("RMR_AUTOTUNE", "0")   # the same kernel per shared layer in both plans: the features are the same bits
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("RMR_FUSE_HEAD", fuse)
+        det = rmr.Detector(pack, nc, (2592, 2048), n, conf_thresh=0.25 if nc == 1 else 0.5)
+        got, _ = det.infer(batch)
+        det.close()
+        assert np.isfinite(got).all()
+        for i in range(min(n, 6)):
+            _check_head(got[i:i + 1], want[i % 3:i % 3 + 1], 2.0, 1e-2)
+        out.append(got)
+    box = np.abs(out[0][:, :4] - out[1][:, :4]).max()
+    score = np.abs(out[0][:, 4:] - out[1][:, 4:]).max()
+    print(f"fused head vs separate launches, {which} x {n}: boxes {box:.2e} px, scores {score:.2e}")
+    assert box <= 1e-3 and score <= 1e-5
+    for i in range(3, n):   # slots with the same image: the same bits, wherever the anchor sits in its workgroup
+        assert np.array_equal(out[0][i], out[0][i % 3])
+
+
 def test_network_on_the_pointwise_kernels(rmr, packs, refs, images, oracle, monkeypatch, tmp_path):
     """conv_pw.hip under the whole network: RMR_TUNE_ONLY=700-799 makes every 1x1 layer it supports
     (K 96..768, N 96..384, among them the two that carry the folded upsample's addend) run on it
