@@ -121,7 +121,8 @@ def rows():
         add("configs[1]", None, f"{R}_bench_config1.json")
     for k in (0, 20):
         bk = jline(f"{R}_bench_crops{k}_{TAG}.json")
-        add(f"K = {k} crops per frame (SURVEY 8d bound)", f"{bk['value']:.0f} frames/s, parity checked: {bk.get('parity_checked')}" if bk else None, f"{R}_bench_crops{k}_{TAG}.json")
+        add(f"K = {k} crops per frame (SURVEY 8d bound)", f"{bk['value']:.0f} frames/s over {bk['steps']} steps (steady state over {bk['steady_state']['seconds']:.0f} s: "
+            f"{bk['steady_state']['value']:.0f}), parity checked: {bk.get('parity_checked')}" if bk else None, f"{R}_bench_crops{k}_{TAG}.json")
     # ---- carried from round 5 (one-off studies, not repeated: the kernels they compare against only got faster)
     ys = text("r05_yardstick.txt")
     if ys:

@@ -105,7 +105,8 @@ def per_op_times(order_log, n_ops):
     for line in open(order_log):
         level, rest = line.rstrip("\n").split(" ", 1)
         f = rest.split("|")
-        if level == "2" and float(f[2]) > 0 and "stem" not in f[1]:   # the first layer has one kernel: it is not in the plan
+        # the first layer has one kernel and the head's fused tail (tag y0) is not a convolution op: neither is in the plan
+        if level == "2" and float(f[2]) > 0 and "stem" not in f[1] and not f[1].endswith(" y0"):
             rows.append((f[1], float(f[4])))
     assert rows and len(rows) % n_ops == 0, f"{len(rows)} profiled conv launches, {n_ops} layers in the plan"
     best = [1e30] * n_ops
