@@ -599,8 +599,9 @@ const T32Tile kT32Tiles[] = {
     // whose 256-row tiles are fewer than the chip's workgroup slots (M25600 N288 at 64 images: 300 tiles of 256 x 96 on 512
     // slots).  20-wide maps only: on 40-wide ones the input ranges leave room for two per CU.
     T32(2, 1, 2, 3, 2, 4, 0, 3),    // 15: 128 x 96
-    // tile 10 with a ring of five slices (one more tap of lookahead for every DMA): fits two per CU up to 40-wide maps
-    T32(4, 1, 2, 3, 4, 5, 0, 2),    // 16: 256 x 96
+    // (tried: tile 10 with a ring of FIVE slices, T32(4, 1, 2, 3, 4, 5, 0, 2) -- one more tap of lookahead for every DMA, fits two
+    // per CU up to 40-wide maps: +0 ... 2 % on M409600 N192 K1728 and M102400 N288 K2592, inside the spread of two runs:
+    // profiles/r06_ring5.txt.  Not kept: it splits the dominant instantiation's layers over two symbols for nothing.)
 #ifdef RMR_T32_PINGPONG
     // 15.. (development builds): the ping-pong form
     { 256, 192, 512, 4, 5, 3, 0, 1, conv_t32pp_kernel<4, 2, 2, 3, 4, 5, 0> },     // 13: 256 x 192

@@ -331,8 +331,7 @@ def test_conv_t32_every_tile(rmr):
     tiles = [(256, 192), (256, 192), (256, 192), (512, 96), (256, 256), (512, 64), (256, 96), (256, 64), (128, 192),
              (128, 192), (256, 96), (128, 128), (256, 64),   # 9..12: two four-wave workgroups per CU
              None, None,                                      # 13, 14: tiles 10 / 9 with rows staged through an input buffer (wide maps only)
-             (128, 96),                                       # 15: three two-wave workgroups per CU (round 6)
-             (256, 96)]                                       # 16: tile 10 with a ring of five
+             (128, 96)]                                       # 15: three two-wave workgroups per CU (round 6)
     for t, shape in enumerate(tiles):
         if shape is None:
             continue
@@ -358,7 +357,6 @@ def test_conv_t32_every_tile(rmr):
     run_case(rmr, 64, 20, 20, 288, 288, 3, 1, True, True, tile=815, seed=84)  # the layer tile 15 is for: 600 tiles on 768 two-wave workgroups
     run_case(rmr, 300, 20, 20, 32, 96, 3, 1, True, False, tile=815, seed=85)  # 938 tiles: some workgroups walk two
     run_case(rmr, 2, 40, 40, 96, 96, 3, 1, True, True, tile=810, seed=86)     # rows of HALF weight blocks (two waves share a KiB), 3 chunks
-    run_case(rmr, 40, 40, 40, 192, 192, 3, 1, True, True, tile=816, seed=87)  # ring of five: 500 tiles, the stream crosses tiles at tap 4
     # split-K (ids 1000 * split + 800 + tile; batches of 1-4 images): one workgroup per (tile, range of chunks), the partial
     # tiles summed in split order by the last arriver; launched twice by the test entry point (the tickets re-arm themselves)
     run_case(rmr, 4, 40, 40, 192, 192, 3, 1, True, True, tile=3000 + 812, seed=90)    # 25 x 3 tiles x 3 splits of 2 chunks

@@ -30,6 +30,18 @@ cloud = scenes.make_cloud(rng, 30000, scenes.K640, scenes.SAMPLE_L2C, (640, 640)
 rects = [[(10 + 150 * i, 200, 120, 100) for i in range(K)]]
 rd = rmr.RobotDetector(car, armor, (640, 640), 12, max_cars=max(K, 1), opt_cars=max(K, 1))
 loc = rmr.Locator(640, 640, scenes.K640, scenes.SAMPLE_L2C, np.eye(4, dtype=np.float32))
+try:
+    rd.detect_batch([img], forced_crops=rects)
+except rmr.RmrError as e:   # the committed plan does not cover this build or these batch sizes: tune here, and say so
+    if "pinned plan" not in str(e):
+        raise
+    rd.close()
+    os.environ.pop("RMR_PLAN", None)
+    for pk in (car, armor):
+        if os.path.exists(pk + ".tune"):
+            os.remove(pk + ".tune")
+    print("(the committed plan does not cover this build: autotuned here)")
+    rd = rmr.RobotDetector(car, armor, (640, 640), 12, max_cars=max(K, 1), opt_cars=max(K, 1))
 lat, ph = [], np.zeros(3)
 for i in range(reps):
     t0 = time.perf_counter()

@@ -43,6 +43,6 @@ python bench.py --dtype fp8 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${R}_
 # configs[1]: batch 1 on the reference sample's 2592 x 2048 frames + 10 k-point clouds from host memory
 python bench.py --config 1 > $OUT/${R}_bench_config1.json 2>> $OUT/bench_fp8.log
 # the bounds SURVEY 8d asks for beside the K = 4 headline: K = 0 (car stage only) and K = 20 (kMaxBatchSize)
-python bench.py --crops 0 --steps 10 --warmup 2 --no-cpu-baseline --no-latency > $OUT/${R}_bench_crops0_${TAG}.json 2>> $OUT/bench_fp8.log
+python bench.py --crops 0 --steps 20 --warmup 20 --no-cpu-baseline --no-latency > $OUT/${R}_bench_crops0_${TAG}.json 2>> $OUT/bench_fp8.log
 python bench.py --crops 20 --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/${R}_bench_crops20_${TAG}.json 2>> $OUT/bench_fp8.log
 tail -c 700 $OUT/${R}_bench_config4_fp8_${TAG}.json
