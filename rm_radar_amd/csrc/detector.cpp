@@ -19,16 +19,20 @@ namespace rmr {
 
 // ---- FrameStage ------------------------------------------------------------------------------------
 
-// The helper thread of a large frame's staging copy: it copies the odd pieces while the calling thread copies the even ones
-// and enqueues every piece's H2D in order.  One job at a time; done[i] is published with release order.
+// The helper thread of a large frame's staging copy.  Pieces are CLAIMED (one atomic counter), not dealt: the calling thread
+// and the helper both take the next unclaimed piece, so a helper that wakes up late (a condition-variable wake-up is tens of
+// microseconds, now and then milliseconds: p99 of configs[1] went to 5 ms when the pieces were dealt odd / even) costs
+// nothing but its share -- the caller simply copies more.  done[i] is published with release order.
 struct FrameStage::Helper {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
     bool stop = false, has_job = false;
+    uint64_t gen = 0;                 // job number (under mu); the claim counter carries it in its upper half
     uint8_t* dst = nullptr;
     const uint8_t* src = nullptr;
-    size_t bytes = 0, piece = 0;
+    size_t bytes = 0, piece = 0, pieces = 0;
+    std::atomic<uint64_t> next{0};    // (job number << 32) | next unclaimed piece
     std::vector<std::atomic<int>> done;
     Helper() : done(64) {
         th = std::thread([this] {
@@ -37,17 +41,9 @@ struct FrameStage::Helper {
                 cv.wait(lk, [this] { return stop || has_job; });
                 if (stop) return;
                 has_job = false;
-                // the job's parameters as locals: behind its last store to done[] the thread touches nothing the next start()
-                // writes (the caller has by then seen every odd piece's flag)
-                uint8_t* const d = dst;
-                const uint8_t* const sp = src;
-                const size_t n = bytes, pc = piece;
-                std::atomic<int>* const flags = done.data();
+                const uint64_t g = gen;
                 lk.unlock();
-                size_t i = 1;
-                for (size_t o = pc; o < n; o += 2 * pc, i += 2) {
-                    std::memcpy(d + o, sp + o, std::min(pc, n - o));
-                    flags[i].store(1, std::memory_order_release);
+                while (copy_next(g)) {
                 }
             }
         });
@@ -60,15 +56,31 @@ struct FrameStage::Helper {
         cv.notify_one();
         th.join();
     }
-    void start(uint8_t* d, const uint8_t* s_, size_t n, size_t pc) {
-        const size_t pieces = (n + pc - 1) / pc;
-        if (done.size() < pieces) done = std::vector<std::atomic<int>>(pieces);
-        for (size_t i = 0; i < pieces; ++i) done[i].store(0, std::memory_order_relaxed);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            dst = d, src = s_, bytes = n, piece = pc, has_job = true;
+    // claims and copies one piece of job g; false: none left, or the counter belongs to a later job (a helper that was away
+    // for a whole frame must not take a piece of a job whose fields it has not read).  A thread that holds a claim on a piece
+    // of job g reads stable fields: start() of job g + 1 only runs after the caller has seen EVERY piece of job g done.
+    bool copy_next(uint64_t g) {
+        uint64_t v = next.load(std::memory_order_acquire);
+        for (;;) {
+            if ((v >> 32) != g || (v & 0xffffffffu) >= pieces) return false;
+            if (next.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) break;
         }
+        const size_t i = (size_t)(v & 0xffffffffu), o = i * piece;
+        std::memcpy(dst + o, src + o, std::min(piece, bytes - o));
+        done[i].store(1, std::memory_order_release);
+        return true;
+    }
+    uint64_t start(uint8_t* d, const uint8_t* s_, size_t n, size_t pc) {
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t np = (n + pc - 1) / pc;
+        if (done.size() < np) done = std::vector<std::atomic<int>>(np);
+        for (size_t i = 0; i < np; ++i) done[i].store(0, std::memory_order_relaxed);
+        dst = d, src = s_, bytes = n, piece = pc, pieces = np;
+        ++gen;
+        next.store(gen << 32, std::memory_order_release);
+        has_job = true;
         cv.notify_one();
+        return gen;
     }
 };
 
@@ -119,16 +131,17 @@ const std::vector<FrameStage::Frame>& FrameStage::stage(hipStream_t s, const rmr
         if (bytes >= 4 * piece) {
             if (off > sent) RMR_HIP(hipMemcpyAsync(dev_.p + sent, pin_.p + sent, off - sent, hipMemcpyHostToDevice, s));
             if (!helper_) helper_ = new Helper();
-            helper_->start(pin_.p + off, im.data, bytes, piece);
-            size_t i = 0;
-            for (size_t o = 0; o < bytes; o += piece, ++i) {
-                const size_t len = std::min(piece, bytes - o);
-                if (i & 1) {
-                    while (!helper_->done[i].load(std::memory_order_acquire)) __builtin_ia32_pause();
-                } else {
-                    std::memcpy(pin_.p + off + o, im.data + o, len);
+            const uint64_t job = helper_->start(pin_.p + off, im.data, bytes, piece);
+            const size_t np = helper_->pieces;
+            size_t queued = 0;   // pieces whose H2D is enqueued: in order, each as soon as it has been copied (by either thread)
+            while (queued < np) {
+                const bool took = helper_->copy_next(job);
+                while (queued < np && helper_->done[queued].load(std::memory_order_acquire)) {
+                    const size_t o = queued * piece;
+                    RMR_HIP(hipMemcpyAsync(dev_.p + off + o, pin_.p + off + o, std::min(piece, bytes - o), hipMemcpyHostToDevice, s));
+                    ++queued;
                 }
-                RMR_HIP(hipMemcpyAsync(dev_.p + off + o, pin_.p + off + o, len, hipMemcpyHostToDevice, s));
+                if (!took && queued < np) __builtin_ia32_pause();   // every piece is claimed: the helper is finishing its last one
             }
             off += (bytes + 255) & ~(size_t)255;
             sent = off;
