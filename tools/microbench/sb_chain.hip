@@ -76,6 +76,51 @@ __global__ __launch_bounds__((WM * WN * WK + LW) * 64) void chain_kernel(const S
     }
 }
 
+// the chain on ONE XCD.  Workgroup ids are dealt round-robin over the eight XCDs (tools/microbench/
+// wg_placement.hip), so of a grid of 8 * P workgroups only those with (id & 7) == 0 stay -- P workgroups behind ONE L2 -- and
+// each walks tiles j, j + P, ... of every layer.  What a layer publishes never has to leave that L2: the barrier's release is
+// a workgroup-scope one (s_waitcnt: the vector L1 is write-through, the stores are in the L2), the arrival an L2 atomic, the
+// acquire invalidates the vector L1 only -- no buffer_wbl2, the instruction that makes the chip-wide barrier cost 8-10 us.
+// P must be co-resident: 32 CUs x one workgroup of this LDS size.
+__device__ __forceinline__ void xcd_barrier(ChainSync* s, unsigned phase, unsigned n_wg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_fetch_add(&s->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (phase + 1) * n_wg;
+        unsigned spins = 0;
+        while (__hip_atomic_load(&s->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) {
+                s->fail = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv: every wave drops its CU's stale L1 lines
+}
+
+template <int WM, int WN, int WK, int MREP, int NREP, int LW>
+__global__ __launch_bounds__((WM * WN * WK + LW) * 64) void chain_xcd_kernel(const SbProblem* __restrict__ probs, const int n_ops, ChainSync* sync, const int P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    if (blockIdx.x & 7) return;            // the other seven XCDs' workgroups leave at once
+    const int j = blockIdx.x >> 3;         // 0 .. P-1, all on XCD 0
+    for (int p = 0; p < n_ops; ++p) {
+        const ConvArgs a = probs[p].a;
+        const SbGeom g = probs[p].g;
+        const int n_tiles = g.mt * g.nt;
+        for (int lid = j; lid < n_tiles; lid += P) {
+            const int mi = g.n_inner ? lid / g.nt : lid % g.mt, ni = g.n_inner ? lid % g.nt : lid / g.mt;
+            sb_tile<WM, WN, WK, MREP, NREP, false, (9 + WK - 1) / WK, LW>(a, g, mi * (WM * MREP * 32), ni * (WN * NREP * 32), smem, lds0);
+            __syncthreads();               // the tile's LDS is reused by the next one
+        }
+        if (p + 1 < n_ops) xcd_barrier(sync, (unsigned)p, (unsigned)P);
+    }
+}
+
 // the same tile walk as one launch per layer (conv_sb_kernel's mapping needs a grid of exactly n_tiles; this one takes the
 // chain's grid so that (a) and (b) differ in the seam only)
 template <int WM, int WN, int WK, int MREP, int NREP, int LW>
@@ -137,9 +182,12 @@ void run_shape(const char* label, std::vector<Layer>& layers, __half* const* buf
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     std::vector<__half> out_a(buf_elems), out_b(buf_elems);
-    float best[2] = {1e30f, 1e30f};
+    CK(hipFuncSetAttribute((const void*)chain_xcd_kernel<WM, WN, WK, MREP, NREP, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    std::vector<__half> out_c(buf_elems);
+    const int P = 32;   // one workgroup per CU of one XCD
+    float best[3] = {1e30f, 1e30f, 1e30f};
     int failed = 0;
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
         for (int rep = 0; rep < reps; ++rep) {
             CK(hipMemset(sync, 0, sizeof(ChainSync)));
             for (int b = 1; b <= n_ops; ++b) CK(hipMemset(bufs[b], 0, buf_elems * 2));
@@ -147,15 +195,17 @@ void run_shape(const char* label, std::vector<Layer>& layers, __half* const* buf
             CK(hipEventRecord(e0));
             if (mode == 0)
                 for (int p = 0; p < n_ops; ++p) one_kernel<WM, WN, WK, MREP, NREP, LW><<<grid, v.threads, lds>>>(dprobs, p);
-            else
+            else if (mode == 1)
                 chain_kernel<WM, WN, WK, MREP, NREP, LW><<<grid, v.threads, lds>>>(dprobs, n_ops, sync);
+            else
+                chain_xcd_kernel<WM, WN, WK, MREP, NREP, LW><<<8 * P, v.threads, lds>>>(dprobs, n_ops, sync, P);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float t;
             CK(hipEventElapsedTime(&t, e0, e1));
             if (rep > 1 && t < best[mode]) best[mode] = t;
         }
-        CK(hipMemcpy(mode == 0 ? out_a.data() : out_b.data(), bufs[n_ops], buf_elems * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(mode == 0 ? out_a.data() : mode == 1 ? out_b.data() : out_c.data(), bufs[n_ops], buf_elems * 2, hipMemcpyDeviceToHost));
         ChainSync h;
         CK(hipMemcpy(&h, sync, sizeof(h), hipMemcpyDeviceToHost));
         failed |= (int)h.fail;
@@ -163,9 +213,12 @@ void run_shape(const char* label, std::vector<Layer>& layers, __half* const* buf
     const bool same = std::memcmp(out_a.data(), out_b.data(), buf_elems * 2) == 0;
     double sum = 0;
     for (size_t i = 0; i < buf_elems; ++i) sum += std::fabs((double)__half2float(out_a[i]));
+    const bool same_c = std::memcmp(out_a.data(), out_c.data(), buf_elems * 2) == 0;
     std::printf("%-28s grid %3d x %3d threads: three launches %6.2f us   one launch with two grid barriers %6.2f us   (%+5.1f %%)   outputs %s%s  [mean |y| %.4f]\n", label,
                 grid, v.threads, best[0] * 1e3, best[1] * 1e3, (best[1] / best[0] - 1.0) * 100.0, same ? "bit-identical" : "DIFFER", failed ? "  BARRIER TIMED OUT" : "",
                 sum / buf_elems);
+    std::printf("%-28s   ... on ONE XCD (32 workgroups walking %d tiles per layer, L2-local barrier): %6.2f us   (%+5.1f %% against the three launches)   outputs %s\n", "",
+                grid, best[2] * 1e3, (best[2] / best[0] - 1.0) * 100.0, same_c ? "bit-identical" : "DIFFER");
     CK(hipFree(dprobs));
     CK(hipFree(sync));
     CK(hipEventDestroy(e0));
