@@ -96,6 +96,17 @@ def rows():
             f"{float(A[2]):.0f} -> {float(B[2]):.0f}); all convolution launches {float(A[3]):.0f} -> {float(B[3]):.0f} TFLOP/s", f"{R}_ab_t32_scalar_state.txt")
     else:
         add("same-box A/B of the conv_t32 K loop", None, f"{R}_ab_t32_scalar_state.txt")
+    abr = text(f"{R}_ab_r05_vs_{R}.txt")
+    rows_ab = abr and [l.split() for l in abr.splitlines() if l.startswith(("r05_", f"{R}_"))]
+    if rows_ab:
+        def mean(tag, col):
+            v = [float(r[col]) for r in rows_ab if r[0].startswith(tag)]
+            return sum(v) / len(v)
+        add("same box, alternating runs, ONE bench.py (this tree's): the round-5 library under its plans against this one",
+            f"frames/s {mean('r05', 1):.0f} -> {mean(R, 1):.0f}; dominant kernel {mean('r05', 8):.0f} -> {mean(R, 8):.0f} TFLOP/s; all convolution launches "
+            f"{mean('r05', 9):.0f} -> {mean(R, 9):.0f}; p50 {mean('r05', 3):.3f} -> {mean(R, 3):.3f} ms (unchanged: round 6 touched the throughput kernels)", f"{R}_ab_r05_vs_{R}.txt")
+    else:
+        add("same-box A/B against the round-5 library", None, f"{R}_ab_r05_vs_{R}.txt")
     tw = text(f"{R}_tile15_and_wsp_pitch.txt")
     if tw:
         us = lambda pat: [float(v) for v in re.findall(pat, tw)]
