@@ -167,3 +167,27 @@ def test_two_ranks_through_the_whole_bench_flow_on_one_gpu():
     assert "FILE transport" in line["gather"], line["gather"]
     assert line["stage_ms_per_step"]["network, armor stage"] > 0        # rank 0's own leg ran to the end
     assert line["value"] <= sum(line["per_rank_frames_per_s"]) * 1.001    # whole-job rate from the slower rank's clock
+
+
+def test_config1_bench_line_is_parity_checked():
+    """`bench.py --config 1` (BASELINE configs[1]: batch 1 on the reference sample's 2592 x 2048 frames + its clouds from host memory,
+    sample calibration, background update first -- samples/main.cpp:12-22,87): the whole mode end to end with a short latency
+    sample.  The line must carry its own parity verdict -- locate and robot assembly of the three frames against the oracle and
+    the network heads of the first against the torch oracle -- and the split of the frame into staging + H2D and the rest."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "1", "--latency-frames", "10", "60", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "configs[1]" in line["config"]["workload"] and "2592x2048" in line["config"]["workload"]
+    assert line["parity_checked"] is True, line["parity"]
+    assert line["parity"]["frames"] == 3 and line["parity"]["assembly_frames"] == 3 and line["parity"]["network_checked"] is True
+    assert line["parity"]["max_xyz_err_m"] <= 1e-3 and line["parity"]["network"]["max_box_err_px"] <= 2.0
+    assert line["parity"]["located"] >= 1                       # the injected returns in front of the background are found
+    assert 0.5 < line["p50_ms_batch1"] < 20 and line["p99_ms_batch1"] >= line["p50_ms_batch1"]
+    split = line["stage_split_ms_per_frame"]
+    assert 0.0 <= split["h2d_fraction_of_frame"] < 0.6
+    assert split["kernels (events around every launch, inputs in HBM)"]["network, armor stage"] > 0
